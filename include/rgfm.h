@@ -1,0 +1,186 @@
+/*
+ * rgfm.h -- C ABI of librgfm_hip.so: the MI355X (gfx950) implementation of the
+ * ratio-guided flow-matching SAMPLER of foubari/ratio_guided_Multimodal_FM.
+ *
+ * The reference has no FFI; its boundary for this path is a Python module API.
+ * Each entry point below replaces the reference call cited next to it, and is
+ * what a ctypes / cffi / pybind stub on the reference side would bind
+ * (INTEGRATION.md shows that stub).
+ *
+ * Conventions
+ *   - every pointer named *_dev / x / y / out / ws is a raw DEVICE pointer to
+ *     contiguous fp32 data that the CALLER owns (PyTorch: tensor.data_ptr());
+ *     the library owns only what *_create allocates and frees it in *_destroy;
+ *   - image tensors are NCHW fp32, exactly as the reference passes them;
+ *   - `stream` is a hipStream_t (PyTorch: torch.cuda.current_stream().cuda_stream);
+ *     all work is enqueued on it, no hidden synchronisation, no allocation
+ *     inside forward/sample calls (graph-capturable);
+ *   - return value: 0 on success, a negative RGFM_E* code otherwise; nothing is
+ *     thrown across the ABI; rgfm_last_error() returns text for the calling
+ *     thread's last failure;
+ *   - one host thread per handle; distinct handles are independent.
+ */
+#ifndef RGFM_H_
+#define RGFM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGFM_ABI_VERSION 1
+
+#define RGFM_OK 0
+#define RGFM_EINVAL (-1)    /* bad argument / unsupported shape          */
+#define RGFM_ENOMEM (-2)    /* hipMalloc failed or workspace too small   */
+#define RGFM_EHIP (-3)      /* a HIP runtime call failed                 */
+#define RGFM_ENODEVICE (-4) /* no gfx950 device visible                  */
+
+#define RGFM_MAX_LEVELS 4
+
+typedef void* rgfm_stream_t; /* hipStream_t */
+
+/* ------------------------------------------------------------------------
+ * Velocity U-Net.  Replaces FlexibleUNet / FlowMatchingUNetMNIST /
+ * FlowMatchingUNetSVHN (reference src/models/unet_flexible.py:111-291) and
+ * UNetMNIST / FlowMatchingUNet (src/models/unet.py:122-305): same
+ * architecture parameters, same parameter tensors.
+ * ---------------------------------------------------------------------- */
+typedef struct rgfm_unet_desc {
+  int32_t in_channels;    /* 1 (MNIST) or 3 (SVHN)                                 */
+  int32_t img_size;       /* 28 or 32 (square)                                     */
+  int32_t model_channels; /* 32 / 64                                               */
+  int32_t num_levels;     /* len(channel_mult)                                     */
+  int32_t channel_mult[RGFM_MAX_LEVELS];
+  int32_t num_res_blocks; /* 2                                                     */
+} rgfm_unet_desc;
+
+typedef struct rgfm_unet rgfm_unet;
+
+/* Number of fp32 values in the parameter blob for `desc`: the tensors of the
+ * reference module's state_dict(), in state_dict() order, each flattened
+ * row-major and concatenated (unet_flexible.py:146-201 registration order). */
+int rgfm_unet_param_floats(const rgfm_unet_desc* desc, size_t* n_floats);
+
+/* Builds the device-side packed weights from the state_dict-order blob
+ * (replaces module construction + load_state_dict, src/utils/__init__.py:25-51).
+ * The blob may be freed once `stream` has been synchronised. */
+int rgfm_unet_create(const rgfm_unet_desc* desc, const float* params_dev, size_t n_floats,
+                     rgfm_stream_t stream, rgfm_unet** out);
+void rgfm_unet_destroy(rgfm_unet* h);
+
+/* Scratch bytes one forward / sample call needs for `batch` rows. */
+int rgfm_unet_workspace_bytes(const rgfm_unet* h, int batch, size_t* bytes);
+
+/* v_out[B,C,H,W] = model(x[B,C,H,W], t)   (FlexibleUNet.forward,
+ * unet_flexible.py:203-261).  t_dev holds t_count in {1, batch} timesteps
+ * (t_count == 1: one t shared by every row, as inside the samplers). */
+int rgfm_unet_forward(rgfm_unet* h, const float* x, const float* t_dev, int t_count, float* v_out,
+                      int batch, void* ws, size_t ws_bytes, rgfm_stream_t stream);
+
+/* Debug / parity hook: after a forward, copy activation `index` (the order the
+ * tensors are produced in; see rgfm_unet_num_activations) as NCHW fp32 into
+ * out_dev.  Only valid when the handle was put in trace mode, which keeps every
+ * activation in its own buffer. */
+int rgfm_unet_set_trace(rgfm_unet* h, int enable);
+int rgfm_unet_num_activations(const rgfm_unet* h, int* n);
+int rgfm_unet_activation_shape(const rgfm_unet* h, int index, int* channels, int* height, int* width);
+int rgfm_unet_read_activation(rgfm_unet* h, int index, int batch, const void* ws, float* out_dev,
+                              rgfm_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Density-ratio estimators.  Replaces RatioEstimatorMNISTSVHN
+ * (src/models/ratio_flexible.py:305-385) and RatioEstimator
+ * (src/models/ratio_estimator.py:96-191), eval mode.
+ * ---------------------------------------------------------------------- */
+#define RGFM_RATIO_MNIST_SVHN 0 /* x[N,1,32,32], y[N,3,32,32], BatchNorm encoders */
+#define RGFM_RATIO_MNIST28 1    /* x[N,1,28,28], y[N,1,28,28], GroupNorm encoders */
+
+#define RGFM_LOSS_DISC 0
+#define RGFM_LOSS_RULSIF 1
+
+#define RGFM_RATIO_OUT_SCORE 0     /* forward(x, y)                      */
+#define RGFM_RATIO_OUT_LOG_RATIO 1 /* log_ratio(x, y)                    */
+#define RGFM_RATIO_OUT_RATIO 2     /* log_ratio(x, y).exp()  (mc_ratios) */
+
+typedef struct rgfm_ratio_desc {
+  int32_t kind;        /* RGFM_RATIO_*      */
+  int32_t feature_dim; /* 256               */
+  int32_t hidden_dim;  /* 512               */
+  int32_t loss_type;   /* RGFM_LOSS_*       */
+} rgfm_ratio_desc;
+
+typedef struct rgfm_ratio rgfm_ratio;
+
+int rgfm_ratio_param_floats(const rgfm_ratio_desc* desc, size_t* n_floats);
+/* Blob = state_dict() order, fp32; BatchNorm `num_batches_tracked` entries are
+ * carried as one fp32 each (value ignored) so that offsets follow the keys. */
+int rgfm_ratio_create(const rgfm_ratio_desc* desc, const float* params_dev, size_t n_floats,
+                      rgfm_stream_t stream, rgfm_ratio** out);
+void rgfm_ratio_destroy(rgfm_ratio* h);
+int rgfm_ratio_workspace_bytes(const rgfm_ratio* h, int n, size_t* bytes);
+/* out[n] per `what` (RGFM_RATIO_OUT_*): forward ratio_flexible.py:347-364,
+ * log_ratio :366-385, and the .exp() of sample_mnist_svhn.py:110-111. */
+int rgfm_ratio_eval(rgfm_ratio* h, const float* x, const float* y, float* out, int n, int what,
+                    void* ws, size_t ws_bytes, rgfm_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Samplers (the Euler/ODE loops).
+ * ---------------------------------------------------------------------- */
+
+/* Unguided Euler integration of one model, in place on x_inout[B,C,H,W]:
+ *   for step in [step_begin, step_end): t = step*(1/num_steps);
+ *       x <- x + model(x, t) * dt
+ * Replaces CFMSchedule.sample (src/utils/flow_utils.py:69-100) and each MC
+ * pre-phase loop (src/sample_mnist_svhn.py:90-95, :99-104;
+ * flow_utils.py:236-241, :245-250). */
+int rgfm_sample_single_workspace_bytes(const rgfm_unet* h, int batch, size_t* bytes);
+int rgfm_sample_single(rgfm_unet* h, float* x_inout, int batch, int num_steps, int step_begin,
+                       int step_end, void* ws, size_t ws_bytes, rgfm_stream_t stream);
+
+/* Paired Euler loop with optional MC importance-weighted guidance, in place on
+ * x_inout[B,Cx,H,W], y_inout[B,Cy,H,W].  Replaces the main loop of
+ * sample_bimodal_guided_mnist_svhn (src/sample_mnist_svhn.py:114-175) and of
+ * sample_bimodal_guided (src/utils/flow_utils.py:263-373).
+ *   mc_x1[N,..], mc_y1[N,..], mc_ratios[N]: terminal MC set; pass n_mc = 0 (and
+ *   null pointers) for guidance_method == 'none'.
+ *   gamma = guidance_strength (not clamped).  Guidance is applied on steps with
+ *   t = step/num_steps > 1e-3, as in the reference. */
+int rgfm_sample_pair_workspace_bytes(const rgfm_unet* hx, const rgfm_unet* hy, int batch, int n_mc,
+                                     size_t* bytes);
+int rgfm_sample_pair(rgfm_unet* hx, rgfm_unet* hy, float* x_inout, float* y_inout,
+                     const float* mc_x1, const float* mc_y1, const float* mc_ratios, int n_mc,
+                     int batch, int num_steps, double gamma, int step_begin, int step_end, void* ws,
+                     size_t ws_bytes, rgfm_stream_t stream);
+
+/* One guidance evaluation on its own (parity hook for sample_mnist_svhn.py:124-171):
+ * vx/vy are overwritten with (1-gamma)*v + gamma*g at time t; weights_out[B,N]
+ * (optional, may be null) receives the normalised importance weights. */
+int rgfm_guidance_workspace_bytes(int batch, int n_mc, size_t* bytes);
+int rgfm_guidance_apply(const float* x, const float* y, float* vx, float* vy, const float* mc_x1,
+                        const float* mc_y1, const float* mc_ratios, int batch, int n_mc, int dim_x,
+                        int dim_y, double t, double gamma, float* weights_out, void* ws,
+                        size_t ws_bytes, rgfm_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Bench support: per-kernel-class device time measured with hipEvents on the
+ * launch stream (bench.py's roofline line).  Timing is off by default.
+ * ---------------------------------------------------------------------- */
+#define RGFM_KCLASS_CONV_MFMA 0 /* conv3x3/1x1 implicit-GEMM (f32 MFMA)  */
+#define RGFM_KCLASS_OTHER 1     /* everything else                       */
+#define RGFM_KCLASS_COUNT 2
+int rgfm_profile_enable(int enable);
+int rgfm_profile_reset(void);
+/* Waits for the recorded events, then returns accumulated milliseconds, launch
+ * count and algorithmic FLOPs (2*MAC) of the class since the last reset. */
+int rgfm_profile_read(int kclass, double* ms, int64_t* launches, double* flops);
+
+int rgfm_abi_version(void);
+const char* rgfm_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGFM_H_ */

@@ -1,0 +1,331 @@
+"""Host plumbing between the nn.Module parameter containers and the C ABI.
+
+PyTorch is used for what it is good at here: owning device memory (parameter
+blob, workspace, I/O tensors) and naming the stream.  All arithmetic happens
+inside librgfm_hip.so.
+"""
+import ctypes
+import weakref
+
+import torch
+
+from . import _lib
+
+_LOSS = {"disc": 0, "rulsif": 1}
+_RATIO_KIND = {"mnist_svhn": 0, "mnist28": 1}
+_RATIO_OUT = {"score": 0, "log_ratio": 1, "ratio": 2}
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_hip(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.RgfmError(
+                "this package runs only on a HIP device (MI355X): got a tensor on "
+                f"'{t.device}'. There is no CPU path; move the model and inputs to 'cuda'.")
+        if t.dtype != torch.float32:
+            raise _lib.RgfmError(f"fp32 tensors expected, got {t.dtype}")
+
+
+class _Workspace:
+    """Grow-only byte buffer per device."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+        return self.buf
+
+
+class _EngineBase:
+    def __init__(self, module):
+        self._module = weakref.ref(module)
+        self._handle = None
+        self._key = None
+        self._blob = None
+        self._ws = _Workspace()
+
+    # engines are per-module caches: never copied or pickled with the module
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (type(None), ())
+
+    def _state_key(self, sd):
+        return tuple((k, v.data_ptr(), v._version, str(v.device)) for k, v in sd.items())
+
+    def _destroy(self):
+        raise NotImplementedError
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                self._destroy()
+        except Exception:
+            pass
+
+    def _blob_from(self, sd, device):
+        parts = [v.detach().reshape(-1).to(device=device, dtype=torch.float32) for v in sd.values()]
+        return torch.cat(parts).contiguous()
+
+    def _check_eval(self, module):
+        if module.training:
+            raise _lib.RgfmError(
+                f"{type(module).__name__} is in training mode; the HIP path implements eval-mode "
+                "semantics only (Dropout = identity, BatchNorm = running statistics). Call .eval().")
+
+
+class UNetEngine(_EngineBase):
+    def desc(self):
+        m = self._module()
+        d = _lib.UNetDesc()
+        d.in_channels, d.img_size, d.model_channels = m.in_channels, m.img_size, m.model_channels
+        d.num_levels = len(m.channel_mult)
+        if d.num_levels > 4:
+            raise _lib.RgfmError("at most 4 resolution levels are supported")
+        for i, c in enumerate(m.channel_mult):
+            d.channel_mult[i] = c
+        d.num_res_blocks = m.num_res_blocks
+        return d
+
+    def handle(self, device):
+        m = self._module()
+        sd = m.state_dict()
+        key = self._state_key(sd)
+        if self._handle is not None and key == self._key:
+            return self._handle
+        L = _lib.lib()
+        if self._handle is not None:
+            self._destroy()
+        d = self.desc()
+        n = ctypes.c_size_t()
+        _lib.check(L.rgfm_unet_param_floats(ctypes.byref(d), ctypes.byref(n)))
+        blob = self._blob_from(sd, device)
+        if blob.numel() != n.value:
+            raise _lib.RgfmError(f"parameter blob has {blob.numel()} floats, library expects {n.value}")
+        h = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(L.rgfm_unet_create(ctypes.byref(d), _ptr(blob), blob.numel(), _stream(device),
+                                          ctypes.byref(h)))
+        self._handle, self._key, self._blob = h, key, blob
+        return h
+
+    def _destroy(self):
+        _lib.lib().rgfm_unet_destroy(self._handle)
+        self._handle = None
+
+    def workspace(self, fn_name, batch, device):
+        L = _lib.lib()
+        n = ctypes.c_size_t()
+        _lib.check(getattr(L, fn_name)(self.handle(device), int(batch), ctypes.byref(n)))
+        return self._ws.get(n.value, device), n.value
+
+    def forward(self, x, t):
+        m = self._module()
+        self._check_eval(m)
+        _require_hip(x, t)
+        if x.dim() != 4 or x.shape[1] != m.in_channels or x.shape[2] != m.img_size or x.shape[3] != m.img_size:
+            raise _lib.RgfmError(f"expected x of shape [B,{m.in_channels},{m.img_size},{m.img_size}], got {tuple(x.shape)}")
+        B = x.shape[0]
+        t = t.reshape(-1)
+        if t.numel() not in (1, B):
+            raise _lib.RgfmError(f"t must have 1 or {B} elements, got {t.numel()}")
+        x = x.contiguous()
+        t = t.contiguous()
+        out = torch.empty_like(x)
+        if B == 0:
+            return out
+        dev = x.device
+        with torch.cuda.device(dev):
+            h = self.handle(dev)
+            ws, nb = self.workspace("rgfm_unet_workspace_bytes", B, dev)
+            _lib.check(_lib.lib().rgfm_unet_forward(h, _ptr(x), _ptr(t), t.numel(), _ptr(out), B,
+                                                    _ptr(ws), nb, _stream(dev)))
+        return out
+
+    # ---- parity hooks -------------------------------------------------
+    def forward_trace(self, x, t):
+        """Forward in trace mode; returns (out, [activation tensors, NCHW])."""
+        dev = x.device
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            h = self.handle(dev)
+            _lib.check(L.rgfm_unet_set_trace(h, 1))
+            try:
+                out = self.forward(x, t)
+                ws, _ = self.workspace("rgfm_unet_workspace_bytes", x.shape[0], dev)
+                n = ctypes.c_int()
+                _lib.check(L.rgfm_unet_num_activations(h, ctypes.byref(n)))
+                acts = []
+                for i in range(n.value):
+                    c, hh, ww = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+                    _lib.check(L.rgfm_unet_activation_shape(h, i, ctypes.byref(c), ctypes.byref(hh),
+                                                            ctypes.byref(ww)))
+                    a = torch.empty(x.shape[0], c.value, hh.value, ww.value, device=dev)
+                    _lib.check(L.rgfm_unet_read_activation(h, i, x.shape[0], _ptr(ws), _ptr(a),
+                                                           _stream(dev)))
+                    acts.append(a)
+            finally:
+                _lib.check(L.rgfm_unet_set_trace(h, 0))
+        return out, acts
+
+
+class RatioEngine(_EngineBase):
+    def __init__(self, module, kind):
+        super().__init__(module)
+        self.kind = kind
+
+    def desc(self):
+        m = self._module()
+        d = _lib.RatioDesc()
+        d.kind = _RATIO_KIND[self.kind]
+        d.feature_dim, d.hidden_dim = m.feature_dim, m.hidden_dim
+        d.loss_type = _LOSS.get(m.loss_type, 0)
+        return d
+
+    def handle(self, device):
+        m = self._module()
+        sd = m.state_dict()
+        key = self._state_key(sd) + (m.loss_type,)
+        if self._handle is not None and key == self._key:
+            return self._handle
+        L = _lib.lib()
+        if self._handle is not None:
+            self._destroy()
+        d = self.desc()
+        n = ctypes.c_size_t()
+        _lib.check(L.rgfm_ratio_param_floats(ctypes.byref(d), ctypes.byref(n)))
+        blob = self._blob_from(sd, device)
+        if blob.numel() != n.value:
+            raise _lib.RgfmError(f"parameter blob has {blob.numel()} floats, library expects {n.value}")
+        h = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(L.rgfm_ratio_create(ctypes.byref(d), _ptr(blob), blob.numel(), _stream(device),
+                                           ctypes.byref(h)))
+        self._handle, self._key, self._blob = h, key, blob
+        return h
+
+    def _destroy(self):
+        _lib.lib().rgfm_ratio_destroy(self._handle)
+        self._handle = None
+
+    def eval(self, x, y, what):
+        m = self._module()
+        self._check_eval(m)
+        _require_hip(x, y)
+        if x.shape[0] != y.shape[0]:
+            raise _lib.RgfmError("x and y must have the same batch size")
+        n = x.shape[0]
+        x, y = x.contiguous(), y.contiguous()
+        out = torch.empty(n, device=x.device, dtype=torch.float32)
+        if n == 0:
+            return out
+        dev = x.device
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            h = self.handle(dev)
+            nb = ctypes.c_size_t()
+            _lib.check(L.rgfm_ratio_workspace_bytes(h, n, ctypes.byref(nb)))
+            ws = self._ws.get(nb.value, dev)
+            _lib.check(L.rgfm_ratio_eval(h, _ptr(x), _ptr(y), _ptr(out), n, _RATIO_OUT[what],
+                                         _ptr(ws), nb.value, _stream(dev)))
+        return out
+
+
+# ---- sampler entry points ------------------------------------------------
+
+_sampler_ws = _Workspace()
+
+
+def sample_single(model, x, num_steps, step_begin=0, step_end=None):
+    """In-place unguided Euler integration of `x` (rgfm_sample_single)."""
+    eng = model._engine
+    eng._check_eval(model)
+    _require_hip(x)
+    if not x.is_contiguous():
+        raise _lib.RgfmError("x must be contiguous (it is updated in place)")
+    if step_end is None:
+        step_end = num_steps
+    B, dev = x.shape[0], x.device
+    if B == 0:
+        return x
+    with torch.cuda.device(dev):
+        h = eng.handle(dev)
+        ws, nb = eng.workspace("rgfm_sample_single_workspace_bytes", B, dev)
+        _lib.check(_lib.lib().rgfm_sample_single(h, _ptr(x), B, int(num_steps), int(step_begin),
+                                                 int(step_end), _ptr(ws), nb, _stream(dev)))
+    return x
+
+
+def sample_pair(fm_x, fm_y, x, y, mc_x1, mc_y1, mc_ratios, num_steps, gamma, step_begin=0,
+                step_end=None):
+    """In-place paired Euler loop with optional MC guidance (rgfm_sample_pair)."""
+    for m in (fm_x, fm_y):
+        m._engine._check_eval(m)
+    _require_hip(x, y, mc_x1, mc_y1, mc_ratios)
+    if not (x.is_contiguous() and y.is_contiguous()):
+        raise _lib.RgfmError("x and y must be contiguous (they are updated in place)")
+    if step_end is None:
+        step_end = num_steps
+    B, dev = x.shape[0], x.device
+    if B == 0:
+        return x, y
+    n_mc = 0 if mc_x1 is None else mc_x1.shape[0]
+    if n_mc:
+        mc_x1, mc_y1, mc_ratios = mc_x1.contiguous(), mc_y1.contiguous(), mc_ratios.contiguous()
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        hx, hy = fm_x._engine.handle(dev), fm_y._engine.handle(dev)
+        nb = ctypes.c_size_t()
+        _lib.check(L.rgfm_sample_pair_workspace_bytes(hx, hy, B, n_mc, ctypes.byref(nb)))
+        ws = _sampler_ws.get(nb.value, dev)
+        _lib.check(L.rgfm_sample_pair(hx, hy, _ptr(x), _ptr(y), _ptr(mc_x1 if n_mc else None),
+                                      _ptr(mc_y1 if n_mc else None),
+                                      _ptr(mc_ratios if n_mc else None), n_mc, B, int(num_steps),
+                                      float(gamma), int(step_begin), int(step_end), _ptr(ws),
+                                      nb.value, _stream(dev)))
+    return x, y
+
+
+def guidance_apply(x, y, vx, vy, mc_x1, mc_y1, mc_ratios, t, gamma, want_weights=False):
+    """One guidance evaluation (parity hook): overwrites vx, vy; returns weights or None."""
+    _require_hip(x, y, vx, vy, mc_x1, mc_y1, mc_ratios)
+    B, N, dev = x.shape[0], mc_x1.shape[0], x.device
+    dx, dy = x[0].numel(), y[0].numel()
+    w = torch.empty(B, N, device=dev) if want_weights else None
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        nb = ctypes.c_size_t()
+        _lib.check(L.rgfm_guidance_workspace_bytes(B, N, ctypes.byref(nb)))
+        ws = _sampler_ws.get(nb.value, dev)
+        _lib.check(L.rgfm_guidance_apply(_ptr(x.contiguous()), _ptr(y.contiguous()), _ptr(vx), _ptr(vy),
+                                         _ptr(mc_x1.contiguous()), _ptr(mc_y1.contiguous()),
+                                         _ptr(mc_ratios.contiguous()), B, N, dx, dy, float(t),
+                                         float(gamma), _ptr(w), _ptr(ws), nb.value, _stream(dev)))
+    return w
+
+
+def profile(enable=None, reset=False):
+    L = _lib.lib()
+    if enable is not None:
+        _lib.check(L.rgfm_profile_enable(1 if enable else 0))
+    if reset:
+        _lib.check(L.rgfm_profile_reset())
+
+
+def profile_read(kclass):
+    ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+    _lib.check(_lib.lib().rgfm_profile_read(kclass, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)))
+    return ms.value, n.value, fl.value

@@ -1,0 +1,6 @@
+"""Model API of the sampler path (mirrors the reference ``src/models``)."""
+from .unet import FlowMatchingUNet, UNetMNIST  # noqa: F401
+from .unet_flexible import (FlexibleUNet, FlowMatchingUNetMNIST, FlowMatchingUNetSVHN,  # noqa: F401
+                            timestep_embedding)
+from .ratio_estimator import RatioEstimator  # noqa: F401
+from .ratio_flexible import RatioEstimatorMNISTSVHN  # noqa: F401
