@@ -1,0 +1,761 @@
+/*
+ * rgfm_oracle.c -- CPU restatement of the reference sampler path (see rgfm_oracle.h).
+ * TEST INFRASTRUCTURE ONLY; parity pinned by tests/test_oracle_golden.py.
+ *
+ * Every function cites the reference lines it follows (paths relative to the
+ * reference repo).  Layout NCHW fp32 like the reference; one OpenMP task per
+ * batch row (rows never interact: per-sample GroupNorm, eval-mode BatchNorm).
+ */
+#include "rgfm_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define NOFMA __attribute__((optimize("fp-contract=off")))
+
+int ro_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+static float* fmalloc(size_t n) { return (float*)malloc((n ? n : 1) * sizeof(float)); }
+
+/* ---------------------------------------------------------------- primitives */
+
+/* F.silu */
+static inline float silu(float v) { return v / (1.0f + expf(-v)); }
+
+/* nn.Linear: y = W x + b, W [out,in] */
+static void linear(const float* W, const float* b, const float* x, int in, int out, float* y) {
+  for (int o = 0; o < out; ++o) {
+    float acc = b ? b[o] : 0.0f;
+    const float* w = W + (size_t)o * in;
+    for (int i = 0; i < in; ++i) acc += w[i] * x[i];
+    y[o] = acc;
+  }
+}
+
+/* nn.Conv2d(k=3, padding=1, stride s) on one sample. in [Ci,H,W] -> out [Co,Ho,Wo]. */
+static void conv3x3(const float* in, int Ci, int H, int W, const float* w, const float* b, int Co,
+                    int stride, float* out) {
+  const int Hp = H + 2, Wp = W + 2;
+  const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+  float* pad = (float*)calloc((size_t)Ci * Hp * Wp, sizeof(float));
+  for (int c = 0; c < Ci; ++c)
+    for (int y = 0; y < H; ++y)
+      memcpy(pad + ((size_t)c * Hp + y + 1) * Wp + 1, in + ((size_t)c * H + y) * W, W * sizeof(float));
+  for (int co = 0; co < Co; ++co) {
+    float* o = out + (size_t)co * Ho * Wo;
+    const float bv = b ? b[co] : 0.0f;
+    for (int i = 0; i < Ho * Wo; ++i) o[i] = bv;
+    for (int ci = 0; ci < Ci; ++ci) {
+      const float* wk = w + ((size_t)co * Ci + ci) * 9;
+      const float* p = pad + (size_t)ci * Hp * Wp;
+      if (stride == 1) {
+        for (int y = 0; y < Ho; ++y) {
+          const float* r0 = p + (size_t)y * Wp;
+          const float* r1 = r0 + Wp;
+          const float* r2 = r1 + Wp;
+          float* orow = o + (size_t)y * Wo;
+          for (int x = 0; x < Wo; ++x) {
+            float a = orow[x];
+            a += wk[0] * r0[x] + wk[1] * r0[x + 1] + wk[2] * r0[x + 2];
+            a += wk[3] * r1[x] + wk[4] * r1[x + 1] + wk[5] * r1[x + 2];
+            a += wk[6] * r2[x] + wk[7] * r2[x + 1] + wk[8] * r2[x + 2];
+            orow[x] = a;
+          }
+        }
+      } else {
+        for (int y = 0; y < Ho; ++y)
+          for (int x = 0; x < Wo; ++x) {
+            float a = o[(size_t)y * Wo + x];
+            for (int ky = 0; ky < 3; ++ky)
+              for (int kx = 0; kx < 3; ++kx)
+                a += wk[ky * 3 + kx] * p[(size_t)(y * stride + ky) * Wp + x * stride + kx];
+            o[(size_t)y * Wo + x] = a;
+          }
+      }
+    }
+  }
+  free(pad);
+}
+
+/* nn.Conv2d(k=1) */
+static void conv1x1(const float* in, int Ci, int HW, const float* w, const float* b, int Co,
+                    float* out) {
+  for (int co = 0; co < Co; ++co) {
+    float* o = out + (size_t)co * HW;
+    for (int i = 0; i < HW; ++i) o[i] = b[co];
+    for (int ci = 0; ci < Ci; ++ci) {
+      const float wv = w[(size_t)co * Ci + ci];
+      const float* p = in + (size_t)ci * HW;
+      for (int i = 0; i < HW; ++i) o[i] += wv * p[i];
+    }
+  }
+}
+
+/* nn.GroupNorm(G, C), eps 1e-5, affine, optionally followed by SiLU; one sample. */
+static void groupnorm(const float* in, int C, int HW, int G, const float* gamma, const float* beta,
+                      int do_silu, float* out) {
+  const int cpg = C / G;
+  for (int g = 0; g < G; ++g) {
+    const float* p = in + (size_t)g * cpg * HW;
+    const size_t n = (size_t)cpg * HW;
+    double s = 0.0;
+    for (size_t i = 0; i < n; ++i) s += p[i];
+    const double mean = s / (double)n;
+    double m2 = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+      const double d = p[i] - mean;
+      m2 += d * d;
+    }
+    const float rstd = (float)(1.0 / sqrt(m2 / (double)n + 1e-5));
+    const float meanf = (float)mean;
+    for (int c = 0; c < cpg; ++c) {
+      const int ch = g * cpg + c;
+      const float a = rstd * gamma[ch];
+      const float bb = beta[ch] - meanf * a;
+      const float* src = in + (size_t)ch * HW;
+      float* dst = out + (size_t)ch * HW;
+      if (do_silu)
+        for (int i = 0; i < HW; ++i) dst[i] = silu(src[i] * a + bb);
+      else
+        for (int i = 0; i < HW; ++i) dst[i] = src[i] * a + bb;
+    }
+  }
+}
+
+/* F.interpolate(scale_factor=2, mode='nearest') */
+static void upsample2(const float* in, int C, int H, int W, float* out) {
+  for (int c = 0; c < C; ++c)
+    for (int y = 0; y < 2 * H; ++y)
+      for (int x = 0; x < 2 * W; ++x)
+        out[((size_t)c * 2 * H + y) * 2 * W + x] = in[((size_t)c * H + (y >> 1)) * W + (x >> 1)];
+}
+
+/* ---------------------------------------------------------------- U-Net */
+
+typedef struct {
+  const float* p;
+} cursor;
+static const float* take(cursor* c, size_t n) {
+  const float* r = c->p;
+  c->p += n;
+  return r;
+}
+
+typedef struct {
+  int cin, cout;
+  const float *n1w, *n1b, *c1w, *c1b, *tw, *tb, *n2w, *n2b, *c2w, *c2b, *sw, *sb;
+} resblock;
+
+static void rb_take(cursor* c, resblock* r, int cin, int cout, int temb) {
+  r->cin = cin;
+  r->cout = cout;
+  r->n1w = take(c, cin);
+  r->n1b = take(c, cin);
+  r->c1w = take(c, (size_t)cout * cin * 9);
+  r->c1b = take(c, cout);
+  r->tw = take(c, (size_t)cout * temb);
+  r->tb = take(c, cout);
+  r->n2w = take(c, cout);
+  r->n2b = take(c, cout);
+  r->c2w = take(c, (size_t)cout * cout * 9);
+  r->c2b = take(c, cout);
+  if (cin != cout) {
+    r->sw = take(c, (size_t)cout * cin);
+    r->sb = take(c, cout);
+  } else {
+    r->sw = r->sb = NULL;
+  }
+}
+
+#define MAXB 32
+typedef struct {
+  int mc, temb, nenc, ndec, ndown, nup;
+  const float *te0w, *te0b, *te2w, *te2b, *icw, *icb, *onw, *onb, *ocw, *ocb;
+  resblock enc[MAXB], mid[2], dec[MAXB];
+  const float *dw[4], *db[4], *uw[4], *ub[4];
+  int dch[4], uch[4];
+  size_t total;
+} unet_plan;
+
+/* Parameter registration order of FlexibleUNet.__init__ (src/models/unet_flexible.py:146-201);
+ * UNetMNIST (src/models/unet.py:155-214) is identical. */
+static void plan_unet(const ro_unet_desc* d, const float* params, unet_plan* P) {
+  cursor c = {params};
+  const int mc = d->model_channels, temb = 4 * mc;
+  memset(P, 0, sizeof(*P));
+  P->mc = mc;
+  P->temb = temb;
+  P->te0w = take(&c, (size_t)temb * mc);
+  P->te0b = take(&c, temb);
+  P->te2w = take(&c, (size_t)temb * temb);
+  P->te2b = take(&c, temb);
+  P->icw = take(&c, (size_t)mc * d->in_channels * 9);
+  P->icb = take(&c, mc);
+  int ch = mc, skips[64], ns = 0;
+  skips[ns++] = ch;
+  int down_ch[4], nd = 0;
+  for (int l = 0; l < d->num_levels; ++l) {
+    const int oc = mc * d->channel_mult[l];
+    for (int r = 0; r < d->num_res_blocks; ++r) {
+      rb_take(&c, &P->enc[P->nenc++], ch, oc, temb);
+      ch = oc;
+      skips[ns++] = ch;
+    }
+    if (l < d->num_levels - 1) {
+      down_ch[nd++] = ch;
+      skips[ns++] = ch;
+    }
+  }
+  for (int i = 0; i < nd; ++i) {
+    P->dch[i] = down_ch[i];
+    P->dw[i] = take(&c, (size_t)down_ch[i] * down_ch[i] * 9);
+    P->db[i] = take(&c, down_ch[i]);
+  }
+  P->ndown = nd;
+  rb_take(&c, &P->mid[0], ch, ch, temb);
+  rb_take(&c, &P->mid[1], ch, ch, temb);
+  int up_ch[4], nu = 0;
+  for (int l = d->num_levels - 1; l >= 0; --l) {
+    const int oc = mc * d->channel_mult[l];
+    for (int i = 0; i < d->num_res_blocks + 1; ++i) {
+      rb_take(&c, &P->dec[P->ndec++], ch + skips[--ns], oc, temb);
+      ch = oc;
+    }
+    if (l > 0) up_ch[nu++] = ch;
+  }
+  for (int i = 0; i < nu; ++i) {
+    P->uch[i] = up_ch[i];
+    P->uw[i] = take(&c, (size_t)up_ch[i] * up_ch[i] * 9);
+    P->ub[i] = take(&c, up_ch[i]);
+  }
+  P->nup = nu;
+  P->onw = take(&c, ch);
+  P->onb = take(&c, ch);
+  P->ocw = take(&c, (size_t)d->in_channels * ch * 9);
+  P->ocb = take(&c, d->in_channels);
+  P->total = (size_t)(c.p - params);
+}
+
+size_t ro_unet_param_floats(const ro_unet_desc* d) {
+  unet_plan P;
+  plan_unet(d, NULL, &P);
+  return P.total;
+}
+
+/* activation table: (channels, size) per index, in production order */
+static int act_table(const ro_unet_desc* d, int* ch_out, int* sz_out) {
+  const int mc = d->model_channels;
+  int n = 0, ch = mc, sz = d->img_size;
+#define PUSH(C, S)        \
+  do {                    \
+    if (ch_out) {         \
+      ch_out[n] = (C);    \
+      sz_out[n] = (S);    \
+    }                     \
+    ++n;                  \
+  } while (0)
+  PUSH(mc, sz);
+  for (int l = 0; l < d->num_levels; ++l) {
+    const int oc = mc * d->channel_mult[l];
+    for (int r = 0; r < d->num_res_blocks; ++r) {
+      PUSH(oc, sz);
+      PUSH(oc, sz);
+      ch = oc;
+    }
+    if (l < d->num_levels - 1) {
+      sz = (sz - 1) / 2 + 1;
+      PUSH(ch, sz);
+    }
+  }
+  for (int i = 0; i < 2; ++i) {
+    PUSH(ch, sz);
+    PUSH(ch, sz);
+  }
+  for (int l = d->num_levels - 1; l >= 0; --l) {
+    const int oc = mc * d->channel_mult[l];
+    for (int i = 0; i < d->num_res_blocks + 1; ++i) {
+      PUSH(oc, sz);
+      PUSH(oc, sz);
+      ch = oc;
+    }
+    if (l > 0) {
+      sz *= 2;
+      PUSH(ch, sz);
+    }
+  }
+  PUSH(d->in_channels, sz);
+#undef PUSH
+  return n;
+}
+
+int ro_unet_num_activations(const ro_unet_desc* d) { return act_table(d, NULL, NULL); }
+
+void ro_unet_activation_shape(const ro_unet_desc* d, int idx, int* c, int* h, int* w) {
+  int ch[256], sz[256];
+  act_table(d, ch, sz);
+  *c = ch[idx];
+  *h = *w = sz[idx];
+}
+
+/* timestep_embedding (src/models/unet_flexible.py:16-36): cos half first. */
+void ro_timestep_embedding(const float* t, int n, int dim, float* out) {
+  const int half = dim / 2;
+  const float neg_log = (float)(-log(10000.0));
+  for (int b = 0; b < n; ++b)
+    for (int i = 0; i < half; ++i) {
+      const float f = expf(((float)i * neg_log) / (float)half);
+      const float a = t[b] * f;
+      out[(size_t)b * dim + i] = cosf(a);
+      out[(size_t)b * dim + half + i] = sinf(a);
+    }
+}
+
+static void store_act(float** acts, int idx, int b, const float* src, size_t n) {
+  if (acts && acts[idx]) memcpy(acts[idx] + (size_t)b * n, src, n * sizeof(float));
+}
+
+/* ResBlock.forward (src/models/unet_flexible.py:71-85), one sample.
+ * x [cin,S,S] -> returns malloc'd [cout,S,S]. st = silu(t_emb). */
+static float* resblock_fwd(const resblock* r, const float* x, int S, const float* st, int temb,
+                           float** acts, int* ai, int b) {
+  const int HW = S * S;
+  const int G1 = r->cin < 8 ? r->cin : 8, G2 = r->cout < 8 ? r->cout : 8;
+  float* a = fmalloc((size_t)r->cin * HW);
+  groupnorm(x, r->cin, HW, G1, r->n1w, r->n1b, 1, a);
+  float* h = fmalloc((size_t)r->cout * HW);
+  conv3x3(a, r->cin, S, S, r->c1w, r->c1b, r->cout, 1, h);
+  free(a);
+  float* tv = fmalloc(r->cout);
+  linear(r->tw, r->tb, st, temb, r->cout, tv);
+  for (int c = 0; c < r->cout; ++c)
+    for (int i = 0; i < HW; ++i) h[(size_t)c * HW + i] += tv[c];
+  free(tv);
+  store_act(acts, (*ai)++, b, h, (size_t)r->cout * HW);
+  float* a2 = fmalloc((size_t)r->cout * HW);
+  groupnorm(h, r->cout, HW, G2, r->n2w, r->n2b, 1, a2);
+  conv3x3(a2, r->cout, S, S, r->c2w, r->c2b, r->cout, 1, h);
+  free(a2);
+  if (r->sw) {
+    float* sk = fmalloc((size_t)r->cout * HW);
+    conv1x1(x, r->cin, HW, r->sw, r->sb, r->cout, sk);
+    for (size_t i = 0; i < (size_t)r->cout * HW; ++i) h[i] += sk[i];
+    free(sk);
+  } else {
+    for (size_t i = 0; i < (size_t)r->cout * HW; ++i) h[i] += x[i];
+  }
+  store_act(acts, (*ai)++, b, h, (size_t)r->cout * HW);
+  return h;
+}
+
+/* FlexibleUNet.forward (src/models/unet_flexible.py:203-261), one sample. */
+static void unet_one(const ro_unet_desc* d, const unet_plan* P, const float* x, float t, float* out,
+                     float** acts, int b) {
+  const int mc = P->mc, temb = P->temb;
+  int S = d->img_size, ai = 0;
+  float emb[512], h1[2048], te[2048], st[2048];
+  ro_timestep_embedding(&t, 1, mc, emb);
+  linear(P->te0w, P->te0b, emb, mc, temb, h1);
+  for (int i = 0; i < temb; ++i) h1[i] = silu(h1[i]);
+  linear(P->te2w, P->te2b, h1, temb, temb, te);
+  for (int i = 0; i < temb; ++i) st[i] = silu(te[i]); /* time_mlp's leading SiLU */
+
+  float* hs[64];
+  int hs_c[64], hs_s[64], ns = 0;
+  int ch = mc;
+  float* h = fmalloc((size_t)mc * S * S);
+  conv3x3(x, d->in_channels, S, S, P->icw, P->icb, mc, 1, h);
+  store_act(acts, ai++, b, h, (size_t)mc * S * S);
+  hs[ns] = h, hs_c[ns] = ch, hs_s[ns] = S, ++ns;
+  int e = 0;
+  for (int l = 0; l < d->num_levels; ++l) {
+    for (int r = 0; r < d->num_res_blocks; ++r) {
+      h = resblock_fwd(&P->enc[e], h, S, st, temb, acts, &ai, b);
+      ch = P->enc[e].cout;
+      ++e;
+      hs[ns] = h, hs_c[ns] = ch, hs_s[ns] = S, ++ns;
+    }
+    if (l < d->num_levels - 1) {
+      const int So = (S - 1) / 2 + 1;
+      float* dn = fmalloc((size_t)ch * So * So);
+      conv3x3(h, ch, S, S, P->dw[l], P->db[l], ch, 2, dn);
+      S = So;
+      h = dn;
+      store_act(acts, ai++, b, h, (size_t)ch * S * S);
+      hs[ns] = h, hs_c[ns] = ch, hs_s[ns] = S, ++ns;
+    }
+  }
+  /* every encoder tensor stays alive in hs (they are the decoder's skips) */
+  float* m1 = resblock_fwd(&P->mid[0], h, S, st, temb, acts, &ai, b);
+  float* m2 = resblock_fwd(&P->mid[1], m1, S, st, temb, acts, &ai, b);
+  free(m1);
+  h = m2;
+  int di = 0, ui = 0;
+  for (int l = d->num_levels - 1; l >= 0; --l) {
+    for (int i = 0; i < d->num_res_blocks + 1; ++i) {
+      --ns;
+      const int sc = hs_c[ns];
+      const size_t HW = (size_t)S * S;
+      float* cat = fmalloc((size_t)(ch + sc) * HW);
+      memcpy(cat, h, (size_t)ch * HW * sizeof(float));
+      memcpy(cat + (size_t)ch * HW, hs[ns], (size_t)sc * HW * sizeof(float));
+      free(h);
+      free(hs[ns]);
+      h = resblock_fwd(&P->dec[di], cat, S, st, temb, acts, &ai, b);
+      free(cat);
+      ch = P->dec[di].cout;
+      ++di;
+    }
+    if (l > 0) {
+      float* up = fmalloc((size_t)ch * 4 * S * S);
+      upsample2(h, ch, S, S, up);
+      free(h);
+      S *= 2;
+      h = fmalloc((size_t)ch * S * S);
+      conv3x3(up, ch, S, S, P->uw[ui], P->ub[ui], ch, 1, h);
+      free(up);
+      ++ui;
+      store_act(acts, ai++, b, h, (size_t)ch * S * S);
+    }
+  }
+  float* a = fmalloc((size_t)ch * S * S);
+  groupnorm(h, ch, S * S, ch < 8 ? ch : 8, P->onw, P->onb, 1, a);
+  conv3x3(a, ch, S, S, P->ocw, P->ocb, d->in_channels, 1, out);
+  free(a);
+  free(h);
+  store_act(acts, ai++, b, out, (size_t)d->in_channels * S * S);
+}
+
+void ro_unet_forward(const ro_unet_desc* d, const float* params, const float* x, const float* t,
+                     int t_count, float* out, int B, float** acts) {
+  unet_plan P;
+  plan_unet(d, params, &P);
+  const size_t n = (size_t)d->in_channels * d->img_size * d->img_size;
+#pragma omp parallel for schedule(dynamic)
+  for (int b = 0; b < B; ++b)
+    unet_one(d, &P, x + b * n, t[t_count == 1 ? 0 : b], out + b * n, acts, b);
+}
+
+/* ---------------------------------------------------------------- ratio estimators */
+
+static void bn_silu(float* h, int C, int HW, const float* w, const float* b, const float* rm,
+                    const float* rv) {
+  /* nn.BatchNorm2d in eval mode (running stats, eps 1e-5) then F.silu */
+  for (int c = 0; c < C; ++c) {
+    const float inv = 1.0f / sqrtf(rv[c] + 1e-5f);
+    for (int i = 0; i < HW; ++i) {
+      const float v = (h[(size_t)c * HW + i] - rm[c]) * inv * w[c] + b[c];
+      h[(size_t)c * HW + i] = silu(v);
+    }
+  }
+}
+
+/* F.max_pool2d(h, 2): floor mode */
+static float* maxpool2(float* in, int C, int* S) {
+  const int Si = *S, So = Si / 2;
+  float* out = fmalloc((size_t)C * So * So);
+  for (int c = 0; c < C; ++c)
+    for (int y = 0; y < So; ++y)
+      for (int x = 0; x < So; ++x) {
+        const float* p = in + ((size_t)c * Si + 2 * y) * Si + 2 * x;
+        out[((size_t)c * So + y) * So + x] = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[Si], p[Si + 1]));
+      }
+  free(in);
+  *S = So;
+  return out;
+}
+
+static void avgpool_fc(const float* h, int C, int HW, const float* fw, const float* fb, int F,
+                       float* out) {
+  float pooled[512];
+  for (int c = 0; c < C; ++c) {
+    float s = 0.0f;
+    for (int i = 0; i < HW; ++i) s += h[(size_t)c * HW + i];
+    pooled[c] = s / (float)HW;
+  }
+  linear(fw, fb, pooled, C, F, out);
+}
+
+/* MNISTEncoder / SVHNEncoder.forward (src/models/ratio_flexible.py:210-232, :271-302).
+ * chans: nconv+1 channel counts; pool_after[i] = max-pool after conv i. */
+static void bn_encoder(cursor* c, const float* img, int S, const int* chans, int nconv,
+                       const int* pool_after, int F, float* feat) {
+  float* h = fmalloc((size_t)chans[0] * S * S);
+  memcpy(h, img, (size_t)chans[0] * S * S * sizeof(float));
+  for (int i = 0; i < nconv; ++i) {
+    const int ci = chans[i], co = chans[i + 1];
+    const float* cw = take(c, (size_t)co * ci * 9);
+    const float* cb = take(c, co);
+    const float* bw = take(c, co);
+    const float* bb = take(c, co);
+    const float* rm = take(c, co);
+    const float* rv = take(c, co);
+    take(c, 1); /* num_batches_tracked */
+    float* o = fmalloc((size_t)co * S * S);
+    conv3x3(h, ci, S, S, cw, cb, co, 1, o);
+    free(h);
+    h = o;
+    bn_silu(h, co, S * S, bw, bb, rm, rv);
+    if (pool_after[i]) h = maxpool2(h, co, &S);
+  }
+  const float* fw = take(c, (size_t)F * chans[nconv]);
+  const float* fb = take(c, F);
+  avgpool_fc(h, chans[nconv], S * S, fw, fb, F, feat);
+  free(h);
+}
+
+/* ImageEncoder.forward (src/models/ratio_estimator.py:67-93): conv-GN-SiLU(-maxpool) x4 */
+static void gn_encoder(cursor* c, const float* img, int S, int F, float* feat) {
+  static const int chans[5] = {1, 32, 64, 128, 128};
+  float* h = fmalloc((size_t)S * S);
+  memcpy(h, img, (size_t)S * S * sizeof(float));
+  for (int i = 0; i < 4; ++i) {
+    const int ci = chans[i], co = chans[i + 1];
+    const float* cw = take(c, (size_t)co * ci * 9);
+    const float* cb = take(c, co);
+    const float* gw = take(c, co);
+    const float* gb = take(c, co);
+    float* o = fmalloc((size_t)co * S * S);
+    conv3x3(h, ci, S, S, cw, cb, co, 1, o);
+    free(h);
+    h = fmalloc((size_t)co * S * S);
+    groupnorm(o, co, S * S, 8, gw, gb, 1, h);
+    free(o);
+    if (i < 3) h = maxpool2(h, co, &S);
+  }
+  const float* fw = take(c, (size_t)F * 128);
+  const float* fb = take(c, F);
+  avgpool_fc(h, 128, S * S, fw, fb, F, feat);
+  free(h);
+}
+
+/* nn.LayerNorm(n), eps 1e-5, then SiLU */
+static void layernorm_silu(float* v, int n, const float* w, const float* b) {
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += v[i];
+  const double mean = s / n;
+  double m2 = 0.0;
+  for (int i = 0; i < n; ++i) m2 += (v[i] - mean) * (v[i] - mean);
+  const float rstd = (float)(1.0 / sqrt(m2 / n + 1e-5)), mf = (float)mean;
+  for (int i = 0; i < n; ++i) v[i] = silu((v[i] - mf) * rstd * w[i] + b[i]);
+}
+
+static inline float logsigmoidf(float x) { return fminf(x, 0.0f) - log1pf(expf(-fabsf(x))); }
+
+/* log_ratio (src/models/ratio_flexible.py:366-385, ratio_estimator.py:160-191) */
+static float finish_ratio(float s, int loss, int what) {
+  if (what == 0) return s;
+  float lr;
+  if (loss == 0) {
+    lr = logsigmoidf(s) - logsigmoidf(-s);
+  } else {
+    const float w = s > 20.0f ? s : log1pf(expf(s)); /* F.softplus, threshold 20 */
+    lr = logf(w + 1e-8f);
+  }
+  return what == 1 ? lr : expf(lr);
+}
+
+static size_t ratio_walk(int kind, int F, int Hd, const float* params, const float* x,
+                         const float* y, int loss, int what, float* out, float* feat) {
+  cursor c = {params};
+  float fx[1024];
+  float* f = fx;
+  if (kind == RO_RATIO_MNIST_SVHN) {
+    static const int cm[5] = {1, 32, 64, 128, 128}, pm[4] = {1, 1, 1, 0};
+    static const int cs[9] = {3, 64, 64, 128, 128, 256, 256, 256, 256};
+    static const int ps[8] = {0, 1, 0, 1, 0, 1, 0, 1};
+    if (x) {
+      bn_encoder(&c, x, 32, cm, 4, pm, F, f);
+      bn_encoder(&c, y, 32, cs, 8, ps, F, f + F);
+    } else {
+      for (int i = 0; i < 4; ++i) take(&c, (size_t)cm[i + 1] * cm[i] * 9 + 5 * cm[i + 1] + 1);
+      take(&c, (size_t)F * 128 + F);
+      for (int i = 0; i < 8; ++i) take(&c, (size_t)cs[i + 1] * cs[i] * 9 + 5 * cs[i + 1] + 1);
+      take(&c, (size_t)F * 256 + F);
+    }
+  } else {
+    if (x) {
+      gn_encoder(&c, x, 28, F, f);
+      gn_encoder(&c, y, 28, F, f + F);
+    } else {
+      static const int ch[5] = {1, 32, 64, 128, 128};
+      for (int e = 0; e < 2; ++e) {
+        for (int i = 0; i < 4; ++i) take(&c, (size_t)ch[i + 1] * ch[i] * 9 + 3 * ch[i + 1]);
+        take(&c, (size_t)F * 128 + F);
+      }
+    }
+  }
+  if (x && feat) memcpy(feat, f, 2 * F * sizeof(float));
+  /* score_net (ratio_flexible.py:332-345: 3 hidden layers; ratio_estimator.py:125-135: 2) */
+  int dims[5], nl;
+  if (kind == RO_RATIO_MNIST_SVHN) {
+    dims[0] = 2 * F, dims[1] = Hd, dims[2] = Hd, dims[3] = Hd / 2, nl = 3;
+  } else {
+    dims[0] = 2 * F, dims[1] = Hd, dims[2] = Hd / 2, nl = 2;
+  }
+  float bufa[2048], bufb[2048];
+  float* cur = f;
+  float* nxt = bufa;
+  for (int l = 0; l < nl; ++l) {
+    const float* w = take(&c, (size_t)dims[l + 1] * dims[l]);
+    const float* b = take(&c, dims[l + 1]);
+    const float* lw = take(&c, dims[l + 1]);
+    const float* lb = take(&c, dims[l + 1]);
+    if (x) {
+      linear(w, b, cur, dims[l], dims[l + 1], nxt);
+      layernorm_silu(nxt, dims[l + 1], lw, lb);
+      cur = nxt;
+      nxt = (nxt == bufa) ? bufb : bufa;
+    }
+  }
+  const float* w = take(&c, dims[nl]);
+  const float* b = take(&c, 1);
+  if (x) {
+    float s;
+    linear(w, b, cur, dims[nl], 1, &s);
+    *out = finish_ratio(s, loss, what);
+  }
+  return (size_t)(c.p - params);
+}
+
+size_t ro_ratio_param_floats(int kind, int feature_dim, int hidden_dim) {
+  return ratio_walk(kind, feature_dim, hidden_dim, NULL, NULL, NULL, 0, 0, NULL, NULL);
+}
+
+void ro_ratio_eval(int kind, int feature_dim, int hidden_dim, int loss, const float* params,
+                   const float* x, const float* y, float* out, int n, int what, float* feat) {
+  const size_t nx = kind == RO_RATIO_MNIST_SVHN ? 1024 : 784;
+  const size_t ny = kind == RO_RATIO_MNIST_SVHN ? 3072 : 784;
+#pragma omp parallel for schedule(dynamic)
+  for (int i = 0; i < n; ++i)
+    ratio_walk(kind, feature_dim, hidden_dim, params, x + i * nx, y + i * ny, loss, what, out + i,
+               feat ? feat + (size_t)i * 2 * feature_dim : NULL);
+}
+
+/* ---------------------------------------------------------------- guidance + Euler */
+
+/* MC importance-weighted guidance block (src/sample_mnist_svhn.py:124-171,
+ * src/utils/flow_utils.py:273-369).  Scalars follow the reference's Python-double
+ * arithmetic, rounded to fp32 where a tensor op consumes them. */
+NOFMA void ro_guidance_apply(const float* x, const float* y, float* vx, float* vy,
+                             const float* mc_x1, const float* mc_y1, const float* mc_ratios, int B,
+                             int N, int dx, int dy, double t, double gamma, float* weights) {
+  const double eps = 1e-3;
+  const double sigma_t = 1.0 - t + eps;
+  const float s2 = (float)(sigma_t * sigma_t);
+  const float tf = (float)t;
+  const float cden = (float)(1.0 - t + eps);
+  const float g1 = (float)(1.0 - gamma), g2 = (float)gamma;
+#pragma omp parallel for schedule(dynamic)
+  for (int b = 0; b < B; ++b) {
+    float* lp = fmalloc(N);
+    float* w = fmalloc(N);
+    const float* xb = x + (size_t)b * dx;
+    const float* yb = y + (size_t)b * dy;
+    for (int i = 0; i < N; ++i) {
+      double sx = 0.0, sy = 0.0;
+      const float* m = mc_x1 + (size_t)i * dx;
+      for (int k = 0; k < dx; ++k) {
+        const float mu = tf * m[k];
+        const float df = xb[k] - mu;
+        sx += (double)(df * df);
+      }
+      m = mc_y1 + (size_t)i * dy;
+      for (int k = 0; k < dy; ++k) {
+        const float mu = tf * m[k];
+        const float df = yb[k] - mu;
+        sy += (double)(df * df);
+      }
+      const float lx = (-0.5f * (float)sx) / s2;
+      const float ly = (-0.5f * (float)sy) / s2;
+      lp[i] = lx + ly;
+    }
+    float mx = lp[0];
+    for (int i = 1; i < N; ++i) mx = fmaxf(mx, lp[i]);
+    float ps = 0.0f, zs = 0.0f;
+    for (int i = 0; i < N; ++i) {
+      w[i] = expf(lp[i] - mx); /* p_joint */
+      ps += w[i];
+      zs += mc_ratios[i] * w[i];
+    }
+    const float pbar = ps / (float)N + 1e-10f;
+    const float zbar = zs / (float)N + 1e-10f;
+    float ws = 0.0f;
+    for (int i = 0; i < N; ++i) {
+      w[i] = (mc_ratios[i] / zbar) * (w[i] / pbar);
+      ws += w[i];
+    }
+    ws += 1e-10f;
+    for (int i = 0; i < N; ++i) w[i] = w[i] / ws;
+    if (weights) memcpy(weights + (size_t)b * N, w, N * sizeof(float));
+    for (int k = 0; k < dx; ++k) {
+      float g = 0.0f;
+      for (int i = 0; i < N; ++i) g += w[i] * ((mc_x1[(size_t)i * dx + k] - xb[k]) / cden);
+      vx[(size_t)b * dx + k] = g1 * vx[(size_t)b * dx + k] + g2 * g;
+    }
+    for (int k = 0; k < dy; ++k) {
+      float g = 0.0f;
+      for (int i = 0; i < N; ++i) g += w[i] * ((mc_y1[(size_t)i * dy + k] - yb[k]) / cden);
+      vy[(size_t)b * dy + k] = g1 * vy[(size_t)b * dy + k] + g2 * g;
+    }
+    free(lp);
+    free(w);
+  }
+}
+
+/* x <- x + v * dt: mul then add, two roundings (sample_mnist_svhn.py:174-175) */
+NOFMA static void euler(float* x, const float* v, size_t n, float dt) {
+  for (size_t i = 0; i < n; ++i) {
+    const float s = v[i] * dt;
+    x[i] = x[i] + s;
+  }
+}
+
+/* CFMSchedule.sample loop (src/utils/flow_utils.py:87-98) / MC pre-phase loops
+ * (src/sample_mnist_svhn.py:90-95, :99-104). */
+void ro_sample_single(const ro_unet_desc* d, const float* params, float* x, int B, int num_steps,
+                      int step_begin, int step_end) {
+  const size_t n = (size_t)B * d->in_channels * d->img_size * d->img_size;
+  const double dt = 1.0 / num_steps;
+  float* v = fmalloc(n);
+  for (int s = step_begin; s < step_end; ++s) {
+    const float t = (float)(s * dt);
+    ro_unet_forward(d, params, x, &t, 1, v, B, NULL);
+    euler(x, v, n, (float)dt);
+  }
+  free(v);
+}
+
+/* main loop of sample_bimodal_guided_mnist_svhn (src/sample_mnist_svhn.py:114-175) and
+ * sample_bimodal_guided (src/utils/flow_utils.py:263-373). */
+void ro_sample_pair(const ro_unet_desc* ddx, const float* px, const ro_unet_desc* ddy,
+                    const float* py, float* x, float* y, const float* mc_x1, const float* mc_y1,
+                    const float* mc_ratios, int n_mc, int B, int num_steps, double gamma,
+                    int step_begin, int step_end) {
+  const int dx = ddx->in_channels * ddx->img_size * ddx->img_size;
+  const int dy = ddy->in_channels * ddy->img_size * ddy->img_size;
+  const double dt = 1.0 / num_steps, eps = 1e-3;
+  float* vx = fmalloc((size_t)B * dx);
+  float* vy = fmalloc((size_t)B * dy);
+  for (int s = step_begin; s < step_end; ++s) {
+    const double t = s * dt;
+    const float tf = (float)t;
+    ro_unet_forward(ddx, px, x, &tf, 1, vx, B, NULL);
+    ro_unet_forward(ddy, py, y, &tf, 1, vy, B, NULL);
+    if (n_mc > 0 && t > eps)
+      ro_guidance_apply(x, y, vx, vy, mc_x1, mc_y1, mc_ratios, B, n_mc, dx, dy, t, gamma, NULL);
+    euler(x, vx, (size_t)B * dx, (float)dt);
+    euler(y, vy, (size_t)B * dy, (float)dt);
+  }
+  free(vx);
+  free(vy);
+}

@@ -1,0 +1,53 @@
+"""Shared test plumbing: synthetic-weight modules, oracle descriptors, fixtures."""
+import functools
+import os
+
+import numpy as np
+import torch
+
+from oracle import oracle as O
+from ratio_guided_multimodal_fm_amd import models as M
+from ratio_guided_multimodal_fm_amd.synth import load_synth, paired_noise  # noqa: F401
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# must match tests/golden/make_golden.py
+SEED_W = {"unet28": 11, "unet28_y": 12, "mnist32": 13, "svhn": 14, "ratio28": 15, "ratio_ms": 16}
+N_PROBE = 256
+
+_CTORS = {
+    "unet28": lambda: M.FlowMatchingUNet(),
+    "unet28_y": lambda: M.FlowMatchingUNet(),
+    "mnist32": lambda: M.FlowMatchingUNetMNIST(32),
+    "svhn": lambda: M.FlowMatchingUNetSVHN(),
+    "ratio28": lambda: M.RatioEstimator(),
+    "ratio_ms": lambda: M.RatioEstimatorMNISTSVHN(),
+}
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def make_module(tag, device=None):
+    m = load_synth(_CTORS[tag](), SEED_W[tag]).eval()
+    return m.to(device) if device is not None else m
+
+
+@functools.lru_cache(maxsize=None)
+def oracle_net(tag):
+    """(descriptor-or-kind, fp32 parameter blob) for the CPU oracle."""
+    m = make_module(tag)
+    blob = O.blob_of(m)
+    if tag.startswith("ratio"):
+        return ("mnist_svhn" if tag == "ratio_ms" else "mnist28"), blob
+    return O.desc_of(m), blob
+
+
+def probe_idx(numel, salt):
+    g = torch.Generator().manual_seed(900 + salt)
+    return torch.randint(0, numel, (N_PROBE,), generator=g).numpy()
+
+
+def maxdiff(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
