@@ -1,0 +1,255 @@
+// conv_mfma.hip -- 3x3 (+ fused 1x1 skip) convolution as an implicit GEMM on the
+// gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, bitwise an fmaf chain).
+//
+// Replaces, fused into ONE kernel per conv, the reference ops of a ResBlock half
+// (src/models/unet_flexible.py:71-85):
+//     GroupNorm-apply + SiLU  (on the load path, from per-(sample,channel) scale/shift)
+//     torch.cat([h, skip],1)  (two source pointers)
+//     F.interpolate(nearest, x2) (folded into the staging addresses, :107)
+//     Conv2d 3x3 stride 1 / stride 2 (:93)  -> MFMA main loop
+//     + bias + time-embedding add (:77-78)
+//     + identity residual or 1x1 skip conv (:85) (extra K-chunks into the same accumulators)
+//     + per-channel GroupNorm partial statistics of the OUTPUT for the next norm.
+//
+// Tiling (DESIGN.md "conv_mfma"): workgroup = 256 threads = 4 waves; block tile =
+// 256 output pixels (4 wave segments of 64) x 32*NT output channels; each wave
+// owns 2 x NT accumulator tiles of 32x32.  K loop: 16 input channels at a time;
+// the (GroupNorm+SiLU-transformed, zero-padded) input halo tile and the 9 taps of
+// weights for those channels are staged in LDS once and reused by all 9 taps.
+// MFMA operand k-permutation: lane half h of k-step s holds channel 8h+s of the
+// chunk, so every lane reads its 8 channels as two ds_read_b128.
+#include "rgfm_device.h"
+
+namespace rgfm {
+
+template <int NT, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;
+  float* sB = smem + a.halo_px * LDP;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const TileGeom g = a.g;
+  const int W = g.W, H = g.H, HW = g.HW;
+
+  int b0, row0;
+  if (g.spt == 1) {
+    b0 = blockIdx.x / g.tps;
+    row0 = (blockIdx.x - b0 * g.tps) * g.th;
+  } else {
+    b0 = blockIdx.x * g.spt;
+    row0 = 0;
+  }
+  const int n0 = blockIdx.y * (32 * NT);
+  const int HR = (MODE == CONV_S2) ? 2 * g.th + 1 : g.th + 2;
+  const int WR = (MODE == CONV_S2) ? 2 * W + 1 : W + 2;
+  int rows_valid = H - row0;
+  if (rows_valid > g.th) rows_valid = g.th;
+  const int nvalid = rows_valid * W;  // valid pixels of this tile (spt == 1)
+
+  // LDS float offsets of this lane's A rows (tap (0,0)) and B rows (tap 0)
+  int abase[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int p = 64 * wave + 32 * mt + l31;
+    int s, q;
+    if (g.spt == 1) {
+      s = 0;
+      q = p < nvalid ? p : nvalid - 1;
+    } else {
+      s = wave;
+      q = (p & 63) < HW ? (p & 63) : HW - 1;
+    }
+    const int r = q / W, x = q - r * W;
+    const int hp = (MODE == CONV_S2) ? (s * HR + 2 * r) * WR + 2 * x : (s * HR + r) * WR + x;
+    abase[mt] = hp * LDP + h * 8;
+  }
+  int bbase[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bbase[nt] = (nt * 32 + l31) * LDP + h * 8;
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  const int cin = a.C0 + a.C1;
+  const int nch_main = cin / KC;
+  const int nch_skip = (a.res_mode == 2) ? (a.R0 + a.R1) / KC : 0;
+
+  for (int ch = 0; ch < nch_main + nch_skip; ++ch) {
+    const bool skip = ch >= nch_main;
+    __syncthreads();  // previous chunk's LDS reads are done
+    if (!skip) {
+      stage_input<MODE>(sA, a.in0, a.in1, a.C0, a.C1, a.Hin, a.Win, a.ab, ch * KC, a.B, b0, row0, H,
+                        W, HR, WR, a.halo_px, tid, 256);
+      const float* wsrc = a.wpk + ((size_t)(blockIdx.y * nch_main + ch) * 9) * (32 * NT * KC);
+      for (int it = tid; it < 9 * 32 * NT * 4; it += 256) {
+        const int row = it >> 2, q = it & 3;
+        *reinterpret_cast<f32x4*>(sB + row * LDP + q * 4) =
+            *reinterpret_cast<const f32x4*>(wsrc + (size_t)it * 4);
+      }
+    } else {
+      const int cs = ch - nch_main;
+      stage_input<CONV_S1>(sA, a.res0, a.res1, a.R0, a.R1, a.Hin, a.Win, nullptr, cs * KC, a.B, b0,
+                           row0, H, W, HR, WR, a.halo_px, tid, 256);
+      const float* wsrc = a.wskip + ((size_t)(blockIdx.y * nch_skip + cs)) * (32 * NT * KC);
+      for (int it = tid; it < 32 * NT * 4; it += 256) {
+        const int row = it >> 2, q = it & 3;
+        *reinterpret_cast<f32x4*>(sB + row * LDP + q * 4) =
+            *reinterpret_cast<const f32x4*>(wsrc + (size_t)it * 4);
+      }
+    }
+    __syncthreads();
+
+    const int tap_lo = skip ? 4 : 0, tap_hi = skip ? 5 : 9;
+    for (int tap = tap_lo; tap < tap_hi; ++tap) {
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      const int aoff = (ky * WR + kx) * LDP;
+      const int boff = (skip ? 0 : tap) * (32 * NT * LDP);
+      float af[2][8], bf[NT][8];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sA + abase[mt] + aoff);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(sA + abase[mt] + aoff + 4);
+        af[mt][0] = v0.x, af[mt][1] = v0.y, af[mt][2] = v0.z, af[mt][3] = v0.w;
+        af[mt][4] = v1.x, af[mt][5] = v1.y, af[mt][6] = v1.z, af[mt][7] = v1.w;
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sB + bbase[nt] + boff);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(sB + bbase[nt] + boff + 4);
+        bf[nt][0] = v0.x, bf[nt][1] = v0.y, bf[nt][2] = v0.z, bf[nt][3] = v0.w;
+        bf[nt][4] = v1.x, bf[nt][5] = v1.y, bf[nt][6] = v1.z, bf[nt][7] = v1.w;
+      }
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][s], bf[nt][s], acc[mt][nt], 0, 0, 0);
+    }
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  // D layout: column (channel) = lane & 31, row (pixel) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+  const int bw = (g.spt == 1) ? b0 : b0 + wave;  // sample of this wave's segment
+  const bool sample_ok = bw < a.B;
+  float addb[NT], addt[NT], eps_[NT], eph_[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int c = n0 + nt * 32 + l31;
+    addb[nt] = a.bias[c];
+    if (a.res_mode == 2) addb[nt] += a.skip_bias[c];
+    addt[nt] = 0.f;
+    if (a.temb && sample_ok) addt[nt] = a.temb[(size_t)(a.temb_per_row ? bw : 0) * a.temb_stride + c];
+    eps_[nt] = a.ep_scale ? a.ep_scale[c] : 1.f;
+    eph_[nt] = a.ep_scale ? a.ep_shift[c] : 0.f;
+  }
+  const size_t pix0 = (g.spt == 1) ? (size_t)b0 * HW + (size_t)row0 * W : (size_t)bw * HW;
+  unsigned vmask[2] = {0u, 0u};
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pl = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;  // pixel within the wave segment
+      const int p = 64 * wave + pl;
+      const bool valid = (g.spt == 1) ? (p < nvalid) : (sample_ok && pl < HW);
+      if (valid) vmask[mt] |= 1u << r;
+      const size_t pix = pix0 + ((g.spt == 1) ? p : pl);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int c = n0 + nt * 32 + l31;
+        float v = (acc[mt][nt][r] + addb[nt]) + addt[nt];
+        if (a.res_mode == 1 && valid) v += a.res0[pix * a.Cout + c];
+        if (a.ep_scale) v = silu_f(v * eps_[nt] + eph_[nt]);
+        acc[mt][nt][r] = v;
+        if (valid) a.out[pix * a.Cout + c] = v;
+      }
+    }
+
+  if (a.stats_out) {
+    int nw;
+    if (g.spt == 1) {
+      nw = nvalid - 64 * wave;
+      nw = nw < 0 ? 0 : (nw > 64 ? 64 : nw);
+    } else {
+      nw = sample_ok ? HW : 0;
+    }
+    const int part = (g.spt == 1) ? (blockIdx.x - b0 * g.tps) * 4 + wave : 0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float s = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (vmask[mt] & (1u << r)) s += acc[mt][nt][r];
+      s += __shfl_xor(s, 32);
+      const float mean = nw > 0 ? s / (float)nw : 0.f;
+      float m2 = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (vmask[mt] & (1u << r)) {
+            const float d = acc[mt][nt][r] - mean;
+            m2 += d * d;
+          }
+      m2 += __shfl_xor(m2, 32);
+      if (h == 0 && sample_ok) {
+        const int c = n0 + nt * 32 + l31;
+        float2 st;
+        st.x = mean;
+        st.y = m2;
+        *reinterpret_cast<float2*>(a.stats_out + (((size_t)bw * g.nparts + part) * a.Cout + c) * 2) = st;
+      }
+    }
+  }
+}
+
+size_t conv_mfma_lds_bytes(const ConvArgs& a) {
+  const int nt = (a.Cout % 64 == 0) ? 2 : 1;
+  return (size_t)(a.halo_px + 9 * 32 * nt) * LDP * sizeof(float);
+}
+
+template <int NT, int MODE>
+static int raise_lds() {
+  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<NT, MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+int conv_mfma_init() {
+  int rc = 0;
+  rc |= raise_lds<1, CONV_S1>();
+  rc |= raise_lds<1, CONV_S2>();
+  rc |= raise_lds<1, CONV_UP2>();
+  rc |= raise_lds<2, CONV_S1>();
+  rc |= raise_lds<2, CONV_S2>();
+  rc |= raise_lds<2, CONV_UP2>();
+  return rc;
+}
+
+void launch_conv_mfma(const ConvArgs& a, int mode, hipStream_t s) {
+  const int nt = (a.Cout % 64 == 0) ? 2 : 1;
+  dim3 grid(geom_num_tiles(a.g, a.B), a.Cout / (32 * nt));
+  const size_t lds = conv_mfma_lds_bytes(a);
+#define LAUNCH(NTV, M) hipLaunchKernelGGL((conv_mfma_kernel<NTV, M>), grid, dim3(256), lds, s, a)
+  if (nt == 2) {
+    if (mode == CONV_S1) LAUNCH(2, CONV_S1);
+    else if (mode == CONV_S2) LAUNCH(2, CONV_S2);
+    else LAUNCH(2, CONV_UP2);
+  } else {
+    if (mode == CONV_S1) LAUNCH(1, CONV_S1);
+    else if (mode == CONV_S2) LAUNCH(1, CONV_S2);
+    else LAUNCH(1, CONV_UP2);
+  }
+#undef LAUNCH
+}
+
+}  // namespace rgfm

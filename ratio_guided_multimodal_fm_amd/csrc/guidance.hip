@@ -1,0 +1,220 @@
+// guidance.hip -- MC importance-weighted guidance (mc_feng) and the Euler update.
+//
+// Replaces the per-step guidance block of the reference samplers
+// (src/sample_mnist_svhn.py:124-171, src/utils/flow_utils.py:273-369), which
+// materialises six [B, N, D] broadcast temporaries per step, by two passes that
+// never leave registers/LDS:
+//   guid_logp : l[b,i] = -0.5 (|x_b - t m^x_i|^2 / s2) + -0.5 (|y_b - t m^y_i|^2 / s2)
+//               (direct differences, no GEMM expansion: late-time weights are
+//               scaled by 1/sigma_t^2 ~ 8e3 and cancellation would flip near-ties)
+//   guid_apply: row-normalised importance weights (exact reference epsilon
+//               sequence), g = sum_i w_i (m_i - x)/(1 - t + eps), blend
+//               (1-gamma) v + gamma g, and optionally the Euler update.
+// Both are HBM/L2-bound elementwise-reduction kernels; the MC set (N x D) stays
+// L2-resident.
+#include "rgfm_device.h"
+
+namespace rgfm {
+
+constexpr int GD = 64;        // D-chunk
+constexpr int GLD = GD + 4;   // LDS row stride (floats): conflict-free b128 rows
+
+__global__ __launch_bounds__(256) void guid_logp_kernel(const GuidanceArgs a) {
+  __shared__ __attribute__((aligned(16))) float sx[32 * GLD];
+  __shared__ __attribute__((aligned(16))) float sm[32 * GLD];
+  const int tid = threadIdx.x;
+  const int tb = tid >> 4, ti = tid & 15;
+  const int bb = blockIdx.x * 32, ib = blockIdx.y * 32;
+  float lsum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  for (int part = 0; part < 2; ++part) {
+    const float* X = part ? a.y : a.x;
+    const float* M = part ? a.mc_y1 : a.mc_x1;
+    const int D = part ? a.dy : a.dx;
+    // chunk partials in fp32 (64 terms), running total in fp64: the sum is then exact
+    // to fp32 rounding, which matters because l is later scaled by 1/sigma_t^2 (up to ~8e3)
+    double S[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    for (int d0 = 0; d0 < D; d0 += GD) {
+      __syncthreads();
+      // 32 rows x 16 float4 for each operand: 512 items each, 2 per thread
+      for (int it = tid; it < 512; it += 256) {
+        const int row = it >> 4, q = it & 15;
+        const int d = d0 + q * 4;
+        f32x4 vx = {0.f, 0.f, 0.f, 0.f}, vm = {0.f, 0.f, 0.f, 0.f};
+        if (d < D) {
+          if (bb + row < a.B) vx = *reinterpret_cast<const f32x4*>(X + (size_t)(bb + row) * D + d);
+          if (ib + row < a.N) {
+            vm = *reinterpret_cast<const f32x4*>(M + (size_t)(ib + row) * D + d);
+            vm.x = __fmul_rn(a.tf, vm.x);  // mu = t * x_1 (rounded, as the reference)
+            vm.y = __fmul_rn(a.tf, vm.y);
+            vm.z = __fmul_rn(a.tf, vm.z);
+            vm.w = __fmul_rn(a.tf, vm.w);
+          }
+        }
+        *reinterpret_cast<f32x4*>(sx + row * GLD + q * 4) = vx;
+        *reinterpret_cast<f32x4*>(sm + row * GLD + q * 4) = vm;
+      }
+      __syncthreads();
+      float c[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+      for (int d = 0; d < GD; d += 4) {
+        f32x4 xv[2], mv[2];
+        xv[0] = *reinterpret_cast<const f32x4*>(sx + tb * GLD + d);
+        xv[1] = *reinterpret_cast<const f32x4*>(sx + (tb + 16) * GLD + d);
+        mv[0] = *reinterpret_cast<const f32x4*>(sm + ti * GLD + d);
+        mv[1] = *reinterpret_cast<const f32x4*>(sm + (ti + 16) * GLD + d);
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            float df;
+            df = xv[p].x - mv[q].x, c[p][q] += df * df;
+            df = xv[p].y - mv[q].y, c[p][q] += df * df;
+            df = xv[p].z - mv[q].z, c[p][q] += df * df;
+            df = xv[p].w - mv[q].w, c[p][q] += df * df;
+          }
+      }
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) S[p][q] += (double)c[p][q];
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) lsum[p][q] = __fadd_rn(lsum[p][q], __fmul_rn(-0.5f, (float)S[p][q]) / a.s2);
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int b = bb + tb + 16 * p, i = ib + ti + 16 * q;
+      if (b < a.B && i < a.N) a.logp[(size_t)b * a.N + i] = lsum[p][q];
+    }
+}
+
+__device__ __forceinline__ float wave_sum_g(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max_g(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// grid (ceil(B/4), ceil(D/1024)); one launch per modality (part).
+__global__ __launch_bounds__(256) void guid_apply_kernel(const GuidanceArgs a, int part) {
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [4][N]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = a.N;
+  const int b0 = blockIdx.x * 4;
+  {  // importance weights of row b0 + wave (sample_mnist_svhn.py:146-156)
+    const int b = b0 + wave;
+    if (b < a.B) {
+      const float* lp = a.logp + (size_t)b * N;
+      float mx = -INFINITY;
+      for (int i = lane; i < N; i += 64) mx = fmaxf(mx, lp[i]);
+      mx = wave_max_g(mx);
+      float ps = 0.f, zs = 0.f;
+      for (int i = lane; i < N; i += 64) {
+        const float p = expf(lp[i] - mx);
+        sw[wave * N + i] = p;
+        ps += p;
+        zs += __fmul_rn(a.mc_ratios[i], p);
+      }
+      ps = wave_sum_g(ps);
+      zs = wave_sum_g(zs);
+      const float pbar = __fadd_rn(ps / (float)N, 1e-10f);
+      const float zbar = __fadd_rn(zs / (float)N, 1e-10f);
+      float ws = 0.f;
+      for (int i = lane; i < N; i += 64) {
+        const float w = __fmul_rn(a.mc_ratios[i] / zbar, sw[wave * N + i] / pbar);
+        sw[wave * N + i] = w;
+        ws += w;
+      }
+      ws = __fadd_rn(wave_sum_g(ws), 1e-10f);
+      for (int i = lane; i < N; i += 64) {
+        const float w = sw[wave * N + i] / ws;
+        sw[wave * N + i] = w;
+        if (a.weights_out && part == 0 && blockIdx.y == 0) a.weights_out[(size_t)b * N + i] = w;
+      }
+    } else {
+      for (int i = lane; i < N; i += 64) sw[wave * N + i] = 0.f;
+    }
+  }
+  __syncthreads();
+
+  const float* X = part ? a.y : a.x;
+  const float* M = part ? a.mc_y1 : a.mc_x1;
+  float* V = part ? a.vy : a.vx;
+  float* XS = part ? a.y_state : a.x_state;
+  const int D = part ? a.dy : a.dx;
+  const int d = blockIdx.y * 1024 + tid * 4;
+  if (d >= D) return;
+  f32x4 xv[4], g[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    g[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    xv[r] = (b0 + r < a.B) ? *reinterpret_cast<const f32x4*>(X + (size_t)(b0 + r) * D + d) : g[r];
+  }
+  for (int i = 0; i < N; ++i) {
+    float w[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w[r] = sw[r * N + i];
+    // exact skip: a zero weight contributes +0 to every sum
+    if (w[0] == 0.f && w[1] == 0.f && w[2] == 0.f && w[3] == 0.f) continue;
+    const f32x4 m = *reinterpret_cast<const f32x4*>(M + (size_t)i * D + d);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (w[r] != 0.f) {
+        g[r].x = __fadd_rn(g[r].x, __fmul_rn(w[r], (m.x - xv[r].x) / a.cden));
+        g[r].y = __fadd_rn(g[r].y, __fmul_rn(w[r], (m.y - xv[r].y) / a.cden));
+        g[r].z = __fadd_rn(g[r].z, __fmul_rn(w[r], (m.z - xv[r].z) / a.cden));
+        g[r].w = __fadd_rn(g[r].w, __fmul_rn(w[r], (m.w - xv[r].w) / a.cden));
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (b0 + r >= a.B) continue;
+    const size_t o = (size_t)(b0 + r) * D + d;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(V + o);
+    f32x4 nv;
+    nv.x = __fadd_rn(__fmul_rn(a.g1, v.x), __fmul_rn(a.g2, g[r].x));
+    nv.y = __fadd_rn(__fmul_rn(a.g1, v.y), __fmul_rn(a.g2, g[r].y));
+    nv.z = __fadd_rn(__fmul_rn(a.g1, v.z), __fmul_rn(a.g2, g[r].z));
+    nv.w = __fadd_rn(__fmul_rn(a.g1, v.w), __fmul_rn(a.g2, g[r].w));
+    if (XS) {
+      f32x4 xs = xv[r];
+      xs.x = __fadd_rn(xs.x, __fmul_rn(nv.x, a.dt));
+      xs.y = __fadd_rn(xs.y, __fmul_rn(nv.y, a.dt));
+      xs.z = __fadd_rn(xs.z, __fmul_rn(nv.z, a.dt));
+      xs.w = __fadd_rn(xs.w, __fmul_rn(nv.w, a.dt));
+      *reinterpret_cast<f32x4*>(XS + o) = xs;
+    } else {
+      *reinterpret_cast<f32x4*>(V + o) = nv;
+    }
+  }
+}
+
+void launch_guidance(const GuidanceArgs& a, hipStream_t s) {
+  dim3 g1((a.B + 31) / 32, (a.N + 31) / 32);
+  hipLaunchKernelGGL(guid_logp_kernel, g1, dim3(256), 0, s, a);
+  const size_t lds = (size_t)4 * a.N * sizeof(float);
+  hipLaunchKernelGGL(guid_apply_kernel, dim3((a.B + 3) / 4, (a.dx + 1023) / 1024), dim3(256), lds, s, a, 0);
+  hipLaunchKernelGGL(guid_apply_kernel, dim3((a.B + 3) / 4, (a.dy + 1023) / 1024), dim3(256), lds, s, a, 1);
+}
+
+// x <- x + v * dt (mul, then add: two roundings like the reference's x_t + v * dt)
+__global__ void euler_kernel(float* x, const float* v, size_t n, float dt) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    x[i] = __fadd_rn(x[i], __fmul_rn(v[i], dt));
+}
+
+void launch_euler(float* x, const float* v, size_t n, float dt, hipStream_t s) {
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(euler_kernel, dim3(blocks), dim3(256), 0, s, x, v, n, dt);
+}
+
+}  // namespace rgfm

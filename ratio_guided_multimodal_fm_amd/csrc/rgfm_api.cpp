@@ -1,0 +1,1055 @@
+// rgfm_api.cpp -- host side of the C ABI declared in include/rgfm.h: parameter
+// ingestion/packing, network walks that enqueue the gfx950 kernels, the Euler
+// sampler loops, and the hipEvent-based kernel-class timers used by bench.py.
+// No PyTorch types, no allocation and no synchronisation inside forward/sample
+// calls (everything is carved from the caller's workspace, stream-ordered).
+#include "../../include/rgfm.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rgfm_kernels.h"
+
+using namespace rgfm;
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) return fail(RGFM_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+extern "C" const char* rgfm_last_error(void) { return g_err.c_str(); }
+extern "C" int rgfm_abi_version(void) { return RGFM_ABI_VERSION; }
+
+// ------------------------------------------------------------------ profiling (bench support)
+namespace {
+struct Prof {
+  bool on = false;
+  std::vector<hipEvent_t> ev;  // pairs
+  std::vector<int> cls;
+  size_t used = 0;
+  double flops[RGFM_KCLASS_COUNT] = {0, 0};
+  double ms_done[RGFM_KCLASS_COUNT] = {0, 0};
+  int64_t launches[RGFM_KCLASS_COUNT] = {0, 0};
+} g_prof;
+
+struct ProfScope {
+  bool active = false;
+  size_t idx = 0;
+  hipStream_t s;
+  ProfScope(int kclass, double flops, hipStream_t stream) : s(stream) {
+    if (!g_prof.on) return;
+    if (g_prof.used + 2 > g_prof.ev.size()) {
+      for (int i = 0; i < 4096; ++i) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        g_prof.ev.push_back(e);
+      }
+      g_prof.cls.resize(g_prof.ev.size() / 2);
+    }
+    idx = g_prof.used;
+    g_prof.used += 2;
+    g_prof.cls[idx / 2] = kclass;
+    g_prof.flops[kclass] += flops;
+    g_prof.launches[kclass] += 1;
+    hipEventRecord(g_prof.ev[idx], s);
+    active = true;
+  }
+  ~ProfScope() {
+    if (active) hipEventRecord(g_prof.ev[idx + 1], s);
+  }
+};
+
+int prof_collect() {
+  for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+    HIP_TRY(hipEventSynchronize(g_prof.ev[i + 1]));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]));
+    g_prof.ms_done[g_prof.cls[i / 2]] += ms;
+  }
+  g_prof.used = 0;
+  return RGFM_OK;
+}
+}  // namespace
+
+extern "C" int rgfm_profile_enable(int enable) {
+  g_prof.on = enable != 0;
+  return RGFM_OK;
+}
+extern "C" int rgfm_profile_reset(void) {
+  int rc = prof_collect();
+  for (int k = 0; k < RGFM_KCLASS_COUNT; ++k) g_prof.flops[k] = g_prof.ms_done[k] = 0, g_prof.launches[k] = 0;
+  return rc;
+}
+extern "C" int rgfm_profile_read(int kclass, double* ms, int64_t* launches, double* flops) {
+  if (kclass < 0 || kclass >= RGFM_KCLASS_COUNT) return fail(RGFM_EINVAL, "bad kernel class %d", kclass);
+  int rc = prof_collect();
+  if (rc) return rc;
+  if (ms) *ms = g_prof.ms_done[kclass];
+  if (launches) *launches = g_prof.launches[kclass];
+  if (flops) *flops = g_prof.flops[kclass];
+  return RGFM_OK;
+}
+
+// ------------------------------------------------------------------ small helpers
+namespace {
+
+struct Bump {  // workspace carving; dry = size-only pass
+  char* base = nullptr;
+  size_t off = 0;
+  size_t cap = 0;
+  bool dry = true;
+  bool overflow = false;
+  float* f(size_t nfloats) {
+    const size_t bytes = (nfloats * sizeof(float) + 255) & ~(size_t)255;
+    const size_t o = off;
+    off += bytes;
+    if (dry) return nullptr;
+    if (off > cap) {
+      overflow = true;
+      return reinterpret_cast<float*>(base);  // never dereferenced: caller checks overflow first
+    }
+    return reinterpret_cast<float*>(base + o);
+  }
+};
+
+struct Tensor {  // NHWC activation + its GroupNorm partial statistics
+  float* data = nullptr;
+  float* stats = nullptr;
+  int C = 0, S = 0;
+};
+
+struct Cursor {
+  size_t off = 0;
+  size_t take(size_t n) {
+    const size_t r = off;
+    off += n;
+    return r;
+  }
+};
+
+struct ConvW {  // one packed conv
+  size_t w_raw = 0, b = 0;  // offsets into the params blob
+  size_t w_pk = 0;          // offset into the packed buffer
+  int cin = 0, cout = 0, taps = 9;
+};
+
+struct ResW {
+  int cin = 0, cout = 0;
+  size_t n1w, n1b, n2w, n2b, tw, tb;
+  ConvW c1, c2, sk;
+  bool has_skip = false;
+  int temb_off = 0;
+};
+
+int nt32_of(int cout) { return (cout % 64 == 0) ? 2 : 1; }
+
+bool on_gfx950() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, dev) != hipSuccess) return false;
+  return strncmp(p.gcnArchName, "gfx950", 6) == 0;
+}
+
+bool g_conv_init = false;
+int ensure_init() {
+  if (!on_gfx950()) return fail(RGFM_ENODEVICE, "librgfm_hip needs a gfx950 (MI355X) device; none is current");
+  if (!g_conv_init) {
+    if (conv_mfma_init() != 0) return fail(RGFM_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    g_conv_init = true;
+  }
+  return RGFM_OK;
+}
+
+}  // namespace
+
+// ================================================================== U-Net
+struct rgfm_unet {
+  rgfm_unet_desc d;
+  float* params = nullptr;  // device copy of the state_dict-order blob
+  float* packed = nullptr;  // packed conv weights
+  float* freqs = nullptr;
+  TimeLinear* lin_dev = nullptr;
+  size_t n_params = 0, n_packed = 0;
+  int mc = 0, temb = 0, nlin = 0, temb_total = 0;
+  size_t te0w, te0b, te2w, te2b, icw, icb, onw, onb, ocw, ocb;
+  std::vector<ResW> enc, mid, dec;
+  std::vector<ConvW> down, up;
+  int final_ch = 0;
+  bool trace = false;
+  struct Act {
+    float* data;
+    int C, S;
+    bool nchw;
+  };
+  std::vector<Act> acts;  // filled by the last (non-dry) run in trace mode
+};
+
+namespace {
+
+// Walks the parameter registration order of FlexibleUNet.__init__
+// (reference src/models/unet_flexible.py:146-201; UNetMNIST, src/models/unet.py:155-214,
+// is identical) and records blob offsets.  Returns the total float count.
+size_t plan_unet(const rgfm_unet_desc& d, rgfm_unet* h) {
+  Cursor c;
+  Cursor pk;
+  const int mc = d.model_channels, temb = 4 * mc;
+  std::vector<ResW> enc, mid, dec;
+  std::vector<ConvW> down, up;
+  int temb_off = 0;
+  auto conv = [&](int cin, int cout, int taps) {
+    ConvW w;
+    w.cin = cin, w.cout = cout, w.taps = taps;
+    w.w_raw = c.take((size_t)cout * cin * taps);
+    w.b = c.take(cout);
+    w.w_pk = pk.take((size_t)cout * cin * taps);
+    return w;
+  };
+  auto res = [&](int cin, int cout) {
+    ResW r;
+    r.cin = cin, r.cout = cout;
+    r.n1w = c.take(cin), r.n1b = c.take(cin);
+    r.c1 = conv(cin, cout, 9);
+    r.tw = c.take((size_t)cout * temb), r.tb = c.take(cout);
+    r.n2w = c.take(cout), r.n2b = c.take(cout);
+    r.c2 = conv(cout, cout, 9);
+    r.has_skip = cin != cout;
+    if (r.has_skip) r.sk = conv(cin, cout, 1);
+    r.temb_off = temb_off;
+    temb_off += cout;
+    return r;
+  };
+  const size_t te0w = c.take((size_t)temb * mc), te0b = c.take(temb);
+  const size_t te2w = c.take((size_t)temb * temb), te2b = c.take(temb);
+  const size_t icw = c.take((size_t)mc * d.in_channels * 9), icb = c.take(mc);
+  int ch = mc;
+  std::vector<int> skips{ch}, down_ch, up_ch;
+  for (int l = 0; l < d.num_levels; ++l) {
+    const int oc = mc * d.channel_mult[l];
+    for (int r = 0; r < d.num_res_blocks; ++r) {
+      enc.push_back(res(ch, oc));
+      ch = oc;
+      skips.push_back(ch);
+    }
+    if (l < d.num_levels - 1) {
+      down_ch.push_back(ch);
+      skips.push_back(ch);
+    }
+  }
+  for (int dc : down_ch) down.push_back(conv(dc, dc, 9));
+  mid.push_back(res(ch, ch));
+  mid.push_back(res(ch, ch));
+  for (int l = d.num_levels - 1; l >= 0; --l) {
+    const int oc = mc * d.channel_mult[l];
+    for (int i = 0; i < d.num_res_blocks + 1; ++i) {
+      dec.push_back(res(ch + skips.back(), oc));
+      skips.pop_back();
+      ch = oc;
+    }
+    if (l > 0) up_ch.push_back(ch);
+  }
+  for (int uc : up_ch) up.push_back(conv(uc, uc, 9));
+  const size_t onw = c.take(ch), onb = c.take(ch);
+  const size_t ocw = c.take((size_t)d.in_channels * ch * 9), ocb = c.take(d.in_channels);
+  if (h) {
+    h->mc = mc, h->temb = temb;
+    h->te0w = te0w, h->te0b = te0b, h->te2w = te2w, h->te2b = te2b;
+    h->icw = icw, h->icb = icb, h->onw = onw, h->onb = onb, h->ocw = ocw, h->ocb = ocb;
+    h->enc = enc, h->mid = mid, h->dec = dec, h->down = down, h->up = up;
+    h->final_ch = ch;
+    h->temb_total = temb_off;
+    h->n_packed = pk.off;
+  }
+  return c.off;
+}
+
+int check_desc(const rgfm_unet_desc* d) {
+  if (!d) return fail(RGFM_EINVAL, "null descriptor");
+  if (d->in_channels != 1 && d->in_channels != 3) return fail(RGFM_EINVAL, "in_channels must be 1 or 3");
+  if (d->num_levels < 1 || d->num_levels > RGFM_MAX_LEVELS) return fail(RGFM_EINVAL, "1..4 levels supported");
+  if (d->model_channels % 32 != 0 || d->model_channels > 256) return fail(RGFM_EINVAL, "model_channels must be a multiple of 32, <= 256");
+  if (d->num_res_blocks < 1 || d->num_res_blocks > 8) return fail(RGFM_EINVAL, "num_res_blocks out of range");
+  if (d->img_size < 4 || d->img_size > 64) return fail(RGFM_EINVAL, "img_size must be in 4..64");
+  int s = d->img_size;
+  for (int l = 0; l < d->num_levels; ++l) {
+    if (d->channel_mult[l] < 1) return fail(RGFM_EINVAL, "channel_mult must be >= 1");
+    if (d->model_channels * d->channel_mult[l] > 256) return fail(RGFM_EINVAL, "at most 256 channels per level");
+    if (l < d->num_levels - 1) {
+      if (s % 2) return fail(RGFM_EINVAL, "odd resolution before a downsample is not supported");
+      s /= 2;
+    }
+  }
+  return RGFM_OK;
+}
+
+void pack_one(const rgfm_unet* h, const ConvW& w, hipStream_t s) {
+  launch_pack_conv(h->params + w.w_raw, h->packed + w.w_pk, w.cout, w.cin, w.taps, nt32_of(w.cout), s);
+}
+
+double conv_flops(int B, int HW, int cout, int kprod) { return 2.0 * B * HW * (double)cout * kprod; }
+
+struct UNetRun {
+  rgfm_unet* h;
+  int B;
+  Bump* ws;
+  hipStream_t s;
+  const float* temb_row;  // table row(s) for this evaluation
+  int temb_per_row;
+  bool dry;
+
+  Tensor new_tensor(int C, int S) {
+    Tensor t;
+    t.C = C, t.S = S;
+    const TileGeom g = make_geom(S, S);
+    t.data = ws->f((size_t)B * S * S * C);
+    t.stats = ws->f((size_t)B * g.nparts * C * 2);
+    return t;
+  }
+  void record(const Tensor& t) {
+    if (!dry && h->trace) h->acts.push_back({t.data, t.C, t.S, false});
+  }
+  float* finalize(const Tensor& a, const Tensor* b, size_t gamma, size_t beta) {
+    const int C = a.C + (b ? b->C : 0);
+    float* ab = ws->f((size_t)B * C * 2);
+    if (dry) return ab;
+    GnFinalizeArgs f{};
+    f.stats0 = a.stats, f.stats1 = b ? b->stats : nullptr;
+    f.C0 = a.C, f.C1 = b ? b->C : 0;
+    f.groups = C < 8 ? C : 8;
+    f.gamma = h->params + gamma, f.beta = h->params + beta;
+    f.ab = ab, f.B = B, f.g = make_geom(a.S, a.S);
+    ProfScope p(RGFM_KCLASS_OTHER, 0, s);
+    launch_gn_finalize(f, s);
+    return ab;
+  }
+  // generic 3x3 conv launch
+  Tensor conv(const Tensor& a, const Tensor* b, const float* ab, const ConvW& w, int mode, const float* temb,
+              int res_mode, const Tensor* r0, const Tensor* r1, const ConvW* sk) {
+    const int So = mode == CONV_S2 ? a.S / 2 : (mode == CONV_UP2 ? a.S * 2 : a.S);
+    Tensor o = new_tensor(w.cout, So);
+    if (dry) return o;
+    ConvArgs c{};
+    c.in0 = a.data, c.in1 = b ? b->data : nullptr;
+    c.C0 = a.C, c.C1 = b ? b->C : 0;
+    c.Hin = c.Win = a.S;
+    c.ab = ab;
+    c.wpk = h->packed + w.w_pk;
+    c.bias = h->params + w.b;
+    c.temb = temb, c.temb_stride = h->temb_total, c.temb_per_row = temb_per_row;
+    c.res_mode = res_mode;
+    if (res_mode) {
+      c.res0 = r0->data, c.res1 = r1 ? r1->data : nullptr;
+      c.R0 = r0->C, c.R1 = r1 ? r1->C : 0;
+    }
+    if (res_mode == 2) c.wskip = h->packed + sk->w_pk, c.skip_bias = h->params + sk->b;
+    c.out = o.data, c.stats_out = o.stats;
+    c.B = B, c.Cout = w.cout;
+    c.g = make_geom(So, So);
+    c.halo_px = mode == CONV_S2 ? c.g.spt * (2 * c.g.th + 1) * (2 * c.g.W + 1) : c.g.spt * (c.g.th + 2) * (c.g.W + 2);
+    const int kprod = 9 * w.cin + (res_mode == 2 ? sk->cin : 0);
+    ProfScope p(RGFM_KCLASS_CONV_MFMA, conv_flops(B, So * So, w.cout, kprod), s);
+    launch_conv_mfma(c, mode, s);
+    return o;
+  }
+  // ResBlock.forward (unet_flexible.py:71-85)
+  Tensor resblock(const ResW& r, const Tensor& a, const Tensor* b) {
+    float* ab1 = finalize(a, b, r.n1w, r.n1b);
+    Tensor h1 = conv(a, b, ab1, r.c1, CONV_S1, dry ? nullptr : temb_row + r.temb_off, 0, nullptr, nullptr, nullptr);
+    record(h1);
+    float* ab2 = finalize(h1, nullptr, r.n2w, r.n2b);
+    Tensor o = conv(h1, nullptr, ab2, r.c2, CONV_S1, nullptr, r.has_skip ? 2 : 1, &a, b, r.has_skip ? &r.sk : nullptr);
+    record(o);
+    return o;
+  }
+
+  // FlexibleUNet.forward (unet_flexible.py:203-261).  Exactly one of v_out / x_state
+  // may be non-null... both allowed: v_out receives the velocity, x_state the Euler update.
+  int run(const float* x, float* v_out, float* x_state, float dt) {
+    const rgfm_unet_desc& d = h->d;
+    if (!dry && h->trace) h->acts.clear();
+    int S = d.img_size;
+    Tensor cur = new_tensor(h->mc, S);
+    if (!dry) {
+      ConvInArgs ci{};
+      ci.x = x, ci.w = h->params + h->icw, ci.bias = h->params + h->icb;
+      ci.out = cur.data, ci.stats_out = cur.stats, ci.B = B, ci.C0 = h->mc, ci.g = make_geom(S, S);
+      ProfScope p(RGFM_KCLASS_OTHER, 0, s);
+      launch_conv_in(ci, d.in_channels, s);
+    }
+    record(cur);
+    std::vector<Tensor> skips{cur};
+    size_t e = 0;
+    for (int l = 0; l < d.num_levels; ++l) {
+      for (int r = 0; r < d.num_res_blocks; ++r) {
+        cur = resblock(h->enc[e++], cur, nullptr);
+        skips.push_back(cur);
+      }
+      if (l < d.num_levels - 1) {
+        cur = conv(cur, nullptr, nullptr, h->down[l], CONV_S2, nullptr, 0, nullptr, nullptr, nullptr);
+        record(cur);
+        skips.push_back(cur);
+      }
+    }
+    cur = resblock(h->mid[0], cur, nullptr);
+    cur = resblock(h->mid[1], cur, nullptr);
+    size_t di = 0, ui = 0;
+    for (int l = d.num_levels - 1; l >= 0; --l) {
+      for (int i = 0; i < d.num_res_blocks + 1; ++i) {
+        Tensor sk = skips.back();
+        skips.pop_back();
+        cur = resblock(h->dec[di++], cur, &sk);
+      }
+      if (l > 0) {
+        cur = conv(cur, nullptr, nullptr, h->up[ui++], CONV_UP2, nullptr, 0, nullptr, nullptr, nullptr);
+        record(cur);
+      }
+    }
+    float* ab = finalize(cur, nullptr, h->onw, h->onb);
+    if (!dry) {
+      ConvOutArgs co{};
+      co.in = cur.data, co.ab = ab, co.w = h->params + h->ocw, co.bias = h->params + h->ocb;
+      co.v_out = v_out, co.x_state = x_state, co.dt = dt, co.B = B, co.Cin = cur.C;
+      co.g = make_geom(cur.S, cur.S);
+      co.halo_px = co.g.spt * (co.g.th + 2) * (co.g.W + 2);
+      ProfScope p(RGFM_KCLASS_OTHER, 0, s);
+      launch_conv_out(co, d.in_channels, s);
+      if (h->trace && v_out) h->acts.push_back({v_out, d.in_channels, cur.S, true});
+    }
+    return RGFM_OK;
+  }
+};
+
+size_t unet_eval_bytes(rgfm_unet* h, int B) {
+  Bump b;
+  UNetRun r{h, B, &b, nullptr, nullptr, 0, true};
+  r.run(nullptr, nullptr, nullptr, 0.f);
+  return b.off;
+}
+
+int launch_time_table(rgfm_unet* h, const float* t_dev, int num_steps, int step_begin, int nt, float* table,
+                      hipStream_t s) {
+  TimeEmbedArgs a{};
+  a.params = h->params, a.freqs = h->freqs, a.mc = h->mc, a.temb = h->temb;
+  a.te0w = (int)h->te0w, a.te0b = (int)h->te0b, a.te2w = (int)h->te2w, a.te2b = (int)h->te2b;
+  a.lin = h->lin_dev, a.nlin = h->nlin, a.total = h->temb_total;
+  a.t_dev = t_dev, a.num_steps = num_steps, a.step_begin = step_begin, a.table = table;
+  ProfScope p(RGFM_KCLASS_OTHER, 0, s);
+  launch_time_embed(a, nt, s);
+  return RGFM_OK;
+}
+
+}  // namespace
+
+extern "C" int rgfm_unet_param_floats(const rgfm_unet_desc* desc, size_t* n_floats) {
+  int rc = check_desc(desc);
+  if (rc) return rc;
+  if (!n_floats) return fail(RGFM_EINVAL, "null output");
+  *n_floats = plan_unet(*desc, nullptr);
+  return RGFM_OK;
+}
+
+extern "C" int rgfm_unet_create(const rgfm_unet_desc* desc, const float* params_dev, size_t n_floats,
+                                rgfm_stream_t stream, rgfm_unet** out) {
+  int rc = check_desc(desc);
+  if (rc) return rc;
+  if (!params_dev || !out) return fail(RGFM_EINVAL, "null argument");
+  if ((rc = ensure_init())) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  rgfm_unet* h = new rgfm_unet();
+  h->d = *desc;
+  h->n_params = plan_unet(*desc, h);
+  if (h->n_params != n_floats) {
+    const size_t want = h->n_params;
+    delete h;
+    return fail(RGFM_EINVAL, "parameter blob has %zu floats, architecture needs %zu", n_floats, want);
+  }
+  for (const auto* v : {&h->enc, &h->mid, &h->dec})
+    for (const ResW& r : *v) {
+      if (r.cin % KC || r.cout % 32) {
+        delete h;
+        return fail(RGFM_EINVAL, "channel counts must be multiples of 16 (in) / 32 (out)");
+      }
+    }
+  auto bail = [&](int code, const char* what) {
+    rgfm_unet_destroy(h);
+    return fail(code, "%s", what);
+  };
+  if (hipMalloc(&h->params, n_floats * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(params)");
+  if (hipMalloc(&h->packed, (h->n_packed + 4) * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(packed)");
+  if (hipMemcpyAsync(h->params, params_dev, n_floats * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return bail(RGFM_EHIP, "hipMemcpyAsync(params)");
+  for (const auto* v : {&h->enc, &h->mid, &h->dec})
+    for (const ResW& r : *v) {
+      pack_one(h, r.c1, s);
+      pack_one(h, r.c2, s);
+      if (r.has_skip) pack_one(h, r.sk, s);
+    }
+  for (const ConvW& w : h->down) pack_one(h, w, s);
+  for (const ConvW& w : h->up) pack_one(h, w, s);
+  // frequency table exp(-ln(1e4) * i / half) in fp32, as torch evaluates it (unet_flexible.py:28-31)
+  const int half = h->mc / 2;
+  std::vector<float> fr(half);
+  const float neg_log = (float)(-std::log(10000.0));
+  for (int i = 0; i < half; ++i) fr[i] = std::exp(((float)i * neg_log) / (float)half);
+  std::vector<TimeLinear> lin;
+  for (const auto* v : {&h->enc, &h->mid, &h->dec})
+    for (const ResW& r : *v) lin.push_back({(int)r.tw, (int)r.tb, r.cout, r.temb_off});
+  h->nlin = (int)lin.size();
+  if (hipMalloc(&h->freqs, half * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(freqs)");
+  if (hipMalloc(&h->lin_dev, lin.size() * sizeof(TimeLinear)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(lin)");
+  if (hipMemcpy(h->freqs, fr.data(), half * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(h->lin_dev, lin.data(), lin.size() * sizeof(TimeLinear), hipMemcpyHostToDevice) != hipSuccess)
+    return bail(RGFM_EHIP, "hipMemcpy(tables)");
+  *out = h;
+  return RGFM_OK;
+}
+
+extern "C" void rgfm_unet_destroy(rgfm_unet* h) {
+  if (!h) return;
+  if (h->params) (void)hipFree(h->params);
+  if (h->packed) (void)hipFree(h->packed);
+  if (h->freqs) (void)hipFree(h->freqs);
+  if (h->lin_dev) (void)hipFree(h->lin_dev);
+  delete h;
+}
+
+static size_t table_bytes(const rgfm_unet* h, int rows) {
+  return (((size_t)rows * h->temb_total * sizeof(float)) + 255) & ~(size_t)255;
+}
+
+extern "C" int rgfm_unet_workspace_bytes(const rgfm_unet* h, int batch, size_t* bytes) {
+  if (!h || !bytes || batch < 1) return fail(RGFM_EINVAL, "bad argument");
+  *bytes = unet_eval_bytes(const_cast<rgfm_unet*>(h), batch) + table_bytes(h, batch);
+  return RGFM_OK;
+}
+
+extern "C" int rgfm_unet_forward(rgfm_unet* h, const float* x, const float* t_dev, int t_count, float* v_out,
+                                 int batch, void* ws, size_t ws_bytes, rgfm_stream_t stream) {
+  if (!h || !x || !t_dev || !v_out || !ws) return fail(RGFM_EINVAL, "null argument");
+  if (batch < 1 || (t_count != 1 && t_count != batch)) return fail(RGFM_EINVAL, "t_count must be 1 or batch");
+  hipStream_t s = (hipStream_t)stream;
+  Bump b;
+  b.base = (char*)ws, b.cap = ws_bytes, b.dry = false;
+  size_t need = 0;
+  rgfm_unet_workspace_bytes(h, batch, &need);
+  if (need > ws_bytes) return fail(RGFM_ENOMEM, "workspace too small: %zu < %zu", ws_bytes, need);
+  float* table = b.f((size_t)t_count * h->temb_total);
+  launch_time_table(h, t_dev, 1, 0, t_count, table, s);
+  UNetRun r{h, batch, &b, s, table, t_count == batch ? 1 : 0, false};
+  int rc = r.run(x, v_out, nullptr, 0.f);
+  if (rc) return rc;
+  HIP_TRY(hipGetLastError());
+  return RGFM_OK;
+}
+
+extern "C" int rgfm_unet_set_trace(rgfm_unet* h, int enable) {
+  if (!h) return fail(RGFM_EINVAL, "null handle");
+  h->trace = enable != 0;
+  h->acts.clear();
+  return RGFM_OK;
+}
+
+namespace {
+void act_table(const rgfm_unet* h, std::vector<std::pair<int, int>>& t) {
+  const rgfm_unet_desc& d = h->d;
+  int S = d.img_size, ch = h->mc;
+  t.push_back({ch, S});
+  for (int l = 0; l < d.num_levels; ++l) {
+    const int oc = h->mc * d.channel_mult[l];
+    for (int r = 0; r < d.num_res_blocks; ++r) {
+      t.push_back({oc, S});
+      t.push_back({oc, S});
+      ch = oc;
+    }
+    if (l < d.num_levels - 1) {
+      S /= 2;
+      t.push_back({ch, S});
+    }
+  }
+  for (int i = 0; i < 4; ++i) t.push_back({ch, S});
+  for (int l = d.num_levels - 1; l >= 0; --l) {
+    const int oc = h->mc * d.channel_mult[l];
+    for (int i = 0; i < d.num_res_blocks + 1; ++i) {
+      t.push_back({oc, S});
+      t.push_back({oc, S});
+      ch = oc;
+    }
+    if (l > 0) {
+      S *= 2;
+      t.push_back({ch, S});
+    }
+  }
+  t.push_back({d.in_channels, S});
+}
+}  // namespace
+
+extern "C" int rgfm_unet_num_activations(const rgfm_unet* h, int* n) {
+  if (!h || !n) return fail(RGFM_EINVAL, "null argument");
+  std::vector<std::pair<int, int>> t;
+  act_table(h, t);
+  *n = (int)t.size();
+  return RGFM_OK;
+}
+
+extern "C" int rgfm_unet_activation_shape(const rgfm_unet* h, int index, int* channels, int* height, int* width) {
+  if (!h) return fail(RGFM_EINVAL, "null handle");
+  std::vector<std::pair<int, int>> t;
+  act_table(h, t);
+  if (index < 0 || index >= (int)t.size()) return fail(RGFM_EINVAL, "activation index out of range");
+  *channels = t[index].first;
+  *height = *width = t[index].second;
+  return RGFM_OK;
+}
+
+extern "C" int rgfm_unet_read_activation(rgfm_unet* h, int index, int batch, const void* ws, float* out_dev,
+                                         rgfm_stream_t stream) {
+  (void)ws;
+  if (!h || !out_dev) return fail(RGFM_EINVAL, "null argument");
+  if (index < 0 || index >= (int)h->acts.size()) return fail(RGFM_EINVAL, "no traced activation %d (run a forward in trace mode first)", index);
+  const auto& a = h->acts[index];
+  hipStream_t s = (hipStream_t)stream;
+  if (a.nchw) HIP_TRY(hipMemcpyAsync(out_dev, a.data, (size_t)batch * a.C * a.S * a.S * sizeof(float), hipMemcpyDeviceToDevice, s));
+  else launch_nhwc_to_nchw(a.data, out_dev, batch, a.C, a.S * a.S, s);
+  return RGFM_OK;
+}
+
+// ================================================================== samplers
+extern "C" int rgfm_sample_single_workspace_bytes(const rgfm_unet* h, int batch, size_t* bytes) {
+  if (!h || !bytes || batch < 1) return fail(RGFM_EINVAL, "bad argument");
+  // the time table is sized for up to 4096 steps per call
+  *bytes = unet_eval_bytes(const_cast<rgfm_unet*>(h), batch) + table_bytes(h, 4096);
+  return RGFM_OK;
+}
+
+extern "C" int rgfm_sample_single(rgfm_unet* h, float* x_inout, int batch, int num_steps, int step_begin,
+                                  int step_end, void* ws, size_t ws_bytes, rgfm_stream_t stream) {
+  if (!h || !x_inout || !ws) return fail(RGFM_EINVAL, "null argument");
+  if (batch < 1 || num_steps < 1 || step_begin < 0 || step_end > num_steps || step_begin > step_end)
+    return fail(RGFM_EINVAL, "bad step range [%d,%d) of %d", step_begin, step_end, num_steps);
+  const int ns = step_end - step_begin;
+  if (ns > 4096) return fail(RGFM_EINVAL, "at most 4096 steps per call");
+  size_t need = 0;
+  rgfm_sample_single_workspace_bytes(h, batch, &need);
+  if (need > ws_bytes) return fail(RGFM_ENOMEM, "workspace too small: %zu < %zu", ws_bytes, need);
+  if (ns == 0) return RGFM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  Bump b;
+  b.base = (char*)ws, b.cap = ws_bytes, b.dry = false;
+  float* table = b.f((size_t)4096 * h->temb_total);
+  launch_time_table(h, nullptr, num_steps, step_begin, ns, table, s);
+  const size_t mark = b.off;
+  const float dt = (float)(1.0 / (double)num_steps);
+  for (int i = 0; i < ns; ++i) {
+    b.off = mark;
+    UNetRun r{h, batch, &b, s, table + (size_t)i * h->temb_total, 0, false};
+    int rc = r.run(x_inout, nullptr, x_inout, dt);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipGetLastError());
+  return RGFM_OK;
+}
+
+extern "C" int rgfm_guidance_workspace_bytes(int batch, int n_mc, size_t* bytes) {
+  if (!bytes || batch < 1 || n_mc < 1) return fail(RGFM_EINVAL, "bad argument");
+  *bytes = (((size_t)batch * n_mc * sizeof(float)) + 255) & ~(size_t)255;
+  return RGFM_OK;
+}
+
+namespace {
+int guidance_launch(const float* x, const float* y, float* vx, float* vy, const float* mx, const float* my,
+                    const float* r, int B, int N, int dx, int dy, double t, double gamma, float* logp,
+                    float* weights_out, float* xs, float* ys, float dt, hipStream_t s) {
+  if (dx % 4 || dy % 4) return fail(RGFM_EINVAL, "flattened image sizes must be multiples of 4");
+  if ((size_t)4 * N * sizeof(float) > 64 * 1024) return fail(RGFM_EINVAL, "n_mc too large (max 4096)");
+  // Python-double scalar arithmetic of the reference (sample_mnist_svhn.py:115,127,135,159,170),
+  // rounded to fp32 where a tensor op consumes it.
+  const double eps = 1e-3;
+  const double sigma_t = 1.0 - t + eps;
+  GuidanceArgs a{};
+  a.x = x, a.y = y, a.vx = vx, a.vy = vy, a.mc_x1 = mx, a.mc_y1 = my, a.mc_ratios = r;
+  a.B = B, a.N = N, a.dx = dx, a.dy = dy;
+  a.tf = (float)t, a.s2 = (float)(sigma_t * sigma_t), a.cden = (float)(1.0 - t + eps);
+  a.g1 = (float)(1.0 - gamma), a.g2 = (float)gamma;
+  a.logp = logp, a.weights_out = weights_out, a.x_state = xs, a.y_state = ys, a.dt = dt;
+  ProfScope p(RGFM_KCLASS_OTHER, 0, s);
+  launch_guidance(a, s);
+  return RGFM_OK;
+}
+}  // namespace
+
+extern "C" int rgfm_guidance_apply(const float* x, const float* y, float* vx, float* vy, const float* mc_x1,
+                                   const float* mc_y1, const float* mc_ratios, int batch, int n_mc, int dim_x,
+                                   int dim_y, double t, double gamma, float* weights_out, void* ws,
+                                   size_t ws_bytes, rgfm_stream_t stream) {
+  if (!x || !y || !vx || !vy || !mc_x1 || !mc_y1 || !mc_ratios || !ws) return fail(RGFM_EINVAL, "null argument");
+  size_t need = 0;
+  int rc = rgfm_guidance_workspace_bytes(batch, n_mc, &need);
+  if (rc) return rc;
+  if (need > ws_bytes) return fail(RGFM_ENOMEM, "workspace too small: %zu < %zu", ws_bytes, need);
+  if ((rc = ensure_init())) return rc;
+  rc = guidance_launch(x, y, vx, vy, mc_x1, mc_y1, mc_ratios, batch, n_mc, dim_x, dim_y, t, gamma, (float*)ws,
+                       weights_out, nullptr, nullptr, 0.f, (hipStream_t)stream);
+  if (rc) return rc;
+  HIP_TRY(hipGetLastError());
+  return RGFM_OK;
+}
+
+extern "C" int rgfm_sample_pair_workspace_bytes(const rgfm_unet* hx, const rgfm_unet* hy, int batch, int n_mc,
+                                                size_t* bytes) {
+  if (!hx || !hy || !bytes || batch < 1 || n_mc < 0) return fail(RGFM_EINVAL, "bad argument");
+  const size_t ex = unet_eval_bytes(const_cast<rgfm_unet*>(hx), batch);
+  const size_t ey = unet_eval_bytes(const_cast<rgfm_unet*>(hy), batch);
+  const size_t dx = (size_t)hx->d.in_channels * hx->d.img_size * hx->d.img_size;
+  const size_t dy = (size_t)hy->d.in_channels * hy->d.img_size * hy->d.img_size;
+  size_t total = table_bytes(hx, 4096) + table_bytes(hy, 4096) + (ex > ey ? ex : ey);
+  total += ((batch * dx * 4 + 255) & ~(size_t)255) + ((batch * dy * 4 + 255) & ~(size_t)255);
+  total += (((size_t)batch * (n_mc > 0 ? n_mc : 1) * 4) + 255) & ~(size_t)255;
+  *bytes = total;
+  return RGFM_OK;
+}
+
+extern "C" int rgfm_sample_pair(rgfm_unet* hx, rgfm_unet* hy, float* x_inout, float* y_inout, const float* mc_x1,
+                                const float* mc_y1, const float* mc_ratios, int n_mc, int batch, int num_steps,
+                                double gamma, int step_begin, int step_end, void* ws, size_t ws_bytes,
+                                rgfm_stream_t stream) {
+  if (!hx || !hy || !x_inout || !y_inout || !ws) return fail(RGFM_EINVAL, "null argument");
+  if (n_mc < 0 || (n_mc > 0 && (!mc_x1 || !mc_y1 || !mc_ratios))) return fail(RGFM_EINVAL, "MC set missing");
+  if (batch < 1 || num_steps < 1 || step_begin < 0 || step_end > num_steps || step_begin > step_end)
+    return fail(RGFM_EINVAL, "bad step range [%d,%d) of %d", step_begin, step_end, num_steps);
+  const int ns = step_end - step_begin;
+  if (ns > 4096) return fail(RGFM_EINVAL, "at most 4096 steps per call");
+  size_t need = 0;
+  rgfm_sample_pair_workspace_bytes(hx, hy, batch, n_mc, &need);
+  if (need > ws_bytes) return fail(RGFM_ENOMEM, "workspace too small: %zu < %zu", ws_bytes, need);
+  if (ns == 0) return RGFM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int dx = hx->d.in_channels * hx->d.img_size * hx->d.img_size;
+  const int dy = hy->d.in_channels * hy->d.img_size * hy->d.img_size;
+  Bump b;
+  b.base = (char*)ws, b.cap = ws_bytes, b.dry = false;
+  float* tx = b.f((size_t)4096 * hx->temb_total);
+  float* ty = b.f((size_t)4096 * hy->temb_total);
+  float* vx = b.f((size_t)batch * dx);
+  float* vy = b.f((size_t)batch * dy);
+  float* logp = b.f((size_t)batch * (n_mc > 0 ? n_mc : 1));
+  launch_time_table(hx, nullptr, num_steps, step_begin, ns, tx, s);
+  launch_time_table(hy, nullptr, num_steps, step_begin, ns, ty, s);
+  const size_t mark = b.off;
+  const double dtd = 1.0 / (double)num_steps;
+  const float dt = (float)dtd;
+  for (int i = 0; i < ns; ++i) {
+    const double t = (double)(step_begin + i) * dtd;
+    const bool guided = n_mc > 0 && t > 1e-3;  // `t > eps` test of the reference (:124)
+    b.off = mark;
+    UNetRun rx{hx, batch, &b, s, tx + (size_t)i * hx->temb_total, 0, false};
+    int rc = rx.run(x_inout, guided ? vx : nullptr, guided ? nullptr : x_inout, dt);
+    if (rc) return rc;
+    b.off = mark;
+    UNetRun ry{hy, batch, &b, s, ty + (size_t)i * hy->temb_total, 0, false};
+    rc = ry.run(y_inout, guided ? vy : nullptr, guided ? nullptr : y_inout, dt);
+    if (rc) return rc;
+    if (guided) {
+      rc = guidance_launch(x_inout, y_inout, vx, vy, mc_x1, mc_y1, mc_ratios, batch, n_mc, dx, dy, t, gamma, logp,
+                           nullptr, x_inout, y_inout, dt, s);
+      if (rc) return rc;
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return RGFM_OK;
+}
+
+// ================================================================== ratio estimators
+struct rgfm_ratio {
+  rgfm_ratio_desc d;
+  float* params = nullptr;
+  float* packed = nullptr;
+  float* bn = nullptr;  // folded BatchNorm scale/shift pairs
+  size_t n_params = 0, n_packed = 0, n_bn = 0;
+  struct Conv {
+    ConvW w;
+    size_t nw = 0, nb = 0;                 // GroupNorm weight/bias (mnist28) or BatchNorm w/b
+    size_t rm = 0, rv = 0;                 // BatchNorm running stats
+    size_t bn_scale = 0, bn_shift = 0;     // offsets into `bn`
+    bool pool_after = false;
+  };
+  struct Encoder {
+    int in_ch = 1, size = 32;
+    std::vector<Conv> convs;
+    size_t fcw = 0, fcb = 0;
+    int fc_in = 0;
+  };
+  Encoder ex, ey;
+  struct Dense {
+    size_t w, b, lw, lb;
+    int in, out;
+  };
+  std::vector<Dense> hidden;
+  size_t headw = 0, headb = 0;
+  int head_in = 0;
+};
+
+namespace {
+
+// Parameter order of RatioEstimatorMNISTSVHN (src/models/ratio_flexible.py:191-208,
+// :241-269, :327-345) and RatioEstimator (src/models/ratio_estimator.py:43-65, :121-135).
+size_t plan_ratio(const rgfm_ratio_desc& d, rgfm_ratio* h) {
+  Cursor c, pk, bn;
+  const int F = d.feature_dim, Hd = d.hidden_dim;
+  auto encoder = [&](int in_ch, int size, const std::vector<int>& chans, const std::vector<int>& pools, bool batchnorm) {
+    rgfm_ratio::Encoder e;
+    e.in_ch = in_ch, e.size = size;
+    int ci = in_ch;
+    for (size_t i = 0; i < chans.size(); ++i) {
+      rgfm_ratio::Conv cv;
+      cv.w.cin = ci, cv.w.cout = chans[i], cv.w.taps = 9;
+      cv.w.w_raw = c.take((size_t)chans[i] * ci * 9);
+      cv.w.b = c.take(chans[i]);
+      if (i > 0) cv.w.w_pk = pk.take((size_t)chans[i] * ci * 9);
+      cv.nw = c.take(chans[i]);
+      cv.nb = c.take(chans[i]);
+      if (batchnorm) {
+        cv.rm = c.take(chans[i]);
+        cv.rv = c.take(chans[i]);
+        c.take(1);  // num_batches_tracked
+        cv.bn_scale = bn.take(chans[i]);
+        cv.bn_shift = bn.take(chans[i]);
+      }
+      cv.pool_after = pools[i] != 0;
+      e.convs.push_back(cv);
+      ci = chans[i];
+    }
+    e.fc_in = ci;
+    e.fcw = c.take((size_t)F * ci);
+    e.fcb = c.take(F);
+    return e;
+  };
+  rgfm_ratio::Encoder ex, ey;
+  std::vector<int> dims;
+  if (d.kind == RGFM_RATIO_MNIST_SVHN) {
+    ex = encoder(1, 32, {32, 64, 128, 128}, {1, 1, 1, 0}, true);
+    ey = encoder(3, 32, {64, 64, 128, 128, 256, 256, 256, 256}, {0, 1, 0, 1, 0, 1, 0, 1}, true);
+    dims = {2 * F, Hd, Hd, Hd / 2};
+  } else {
+    ex = encoder(1, 28, {32, 64, 128, 128}, {1, 1, 1, 0}, false);
+    ey = encoder(1, 28, {32, 64, 128, 128}, {1, 1, 1, 0}, false);
+    dims = {2 * F, Hd, Hd / 2};
+  }
+  std::vector<rgfm_ratio::Dense> hidden;
+  for (size_t l = 0; l + 1 < dims.size(); ++l) {
+    rgfm_ratio::Dense dn;
+    dn.in = dims[l], dn.out = dims[l + 1];
+    dn.w = c.take((size_t)dn.in * dn.out), dn.b = c.take(dn.out);
+    dn.lw = c.take(dn.out), dn.lb = c.take(dn.out);
+    hidden.push_back(dn);
+  }
+  const size_t headw = c.take(dims.back()), headb = c.take(1);
+  if (h) {
+    h->ex = ex, h->ey = ey, h->hidden = hidden, h->headw = headw, h->headb = headb, h->head_in = dims.back();
+    h->n_packed = pk.off, h->n_bn = bn.off;
+  }
+  return c.off;
+}
+
+int check_ratio_desc(const rgfm_ratio_desc* d) {
+  if (!d) return fail(RGFM_EINVAL, "null descriptor");
+  if (d->kind != RGFM_RATIO_MNIST_SVHN && d->kind != RGFM_RATIO_MNIST28) return fail(RGFM_EINVAL, "unknown ratio kind");
+  if (d->feature_dim % 64 || d->hidden_dim % 128 || d->feature_dim > 512 || d->hidden_dim > 1024)
+    return fail(RGFM_EINVAL, "feature_dim must be a multiple of 64 (<=512), hidden_dim of 128 (<=1024)");
+  if (d->loss_type != RGFM_LOSS_DISC && d->loss_type != RGFM_LOSS_RULSIF) return fail(RGFM_EINVAL, "unknown loss_type");
+  return RGFM_OK;
+}
+
+struct RatioRun {
+  rgfm_ratio* h;
+  int n;
+  Bump* ws;
+  hipStream_t s;
+  bool dry;
+
+  // one encoder: image NCHW -> features written at feat[:, col0 : col0+F] (row stride 2F)
+  void encode(const rgfm_ratio::Encoder& e, const float* img, float* feat, int col0) {
+    const bool gn = h->d.kind == RGFM_RATIO_MNIST28;
+    const int F = h->d.feature_dim;
+    int S = e.size;
+    Tensor cur;
+    float* ab = nullptr;  // pending GroupNorm scale/shift of `cur` (mnist28)
+    for (size_t i = 0; i < e.convs.size(); ++i) {
+      const rgfm_ratio::Conv& cv = e.convs[i];
+      const TileGeom g = make_geom(S, S);
+      Tensor o;
+      o.C = cv.w.cout, o.S = S;
+      o.data = ws->f((size_t)n * S * S * o.C);
+      o.stats = gn ? ws->f((size_t)n * g.nparts * o.C * 2) : nullptr;
+      if (!dry) {
+        const float* es = gn ? nullptr : h->bn + cv.bn_scale;
+        const float* eh = gn ? nullptr : h->bn + cv.bn_shift;
+        if (i == 0) {
+          ConvInArgs ci{};
+          ci.x = img, ci.w = h->params + cv.w.w_raw, ci.bias = h->params + cv.w.b;
+          ci.ep_scale = es, ci.ep_shift = eh;
+          ci.out = o.data, ci.stats_out = o.stats, ci.B = n, ci.C0 = o.C, ci.g = g;
+          ProfScope p(RGFM_KCLASS_OTHER, 0, s);
+          launch_conv_in(ci, e.in_ch, s);
+        } else {
+          ConvArgs c{};
+          c.in0 = cur.data, c.C0 = cur.C, c.Hin = c.Win = S;
+          c.wpk = h->packed + cv.w.w_pk, c.bias = h->params + cv.w.b;
+          c.ep_scale = es, c.ep_shift = eh;
+          c.out = o.data, c.stats_out = o.stats, c.B = n, c.Cout = o.C, c.g = g;
+          c.halo_px = g.spt * (g.th + 2) * (g.W + 2);
+          ProfScope p(RGFM_KCLASS_CONV_MFMA, conv_flops(n, S * S, o.C, 9 * cur.C), s);
+          launch_conv_mfma(c, CONV_S1, s);
+        }
+      }
+      cur = o;
+      if (gn) {
+        ab = ws->f((size_t)n * o.C * 2);
+        if (!dry) {
+          GnFinalizeArgs f{};
+          f.stats0 = o.stats, f.C0 = o.C, f.groups = 8;
+          f.gamma = h->params + cv.nw, f.beta = h->params + cv.nb, f.ab = ab, f.B = n, f.g = g;
+          ProfScope p(RGFM_KCLASS_OTHER, 0, s);
+          launch_gn_finalize(f, s);
+        }
+      }
+      if (cv.pool_after) {
+        Tensor pl;
+        pl.C = cur.C, pl.S = S / 2;
+        pl.data = ws->f((size_t)n * pl.S * pl.S * pl.C);
+        if (!dry) {
+          ProfScope p(RGFM_KCLASS_OTHER, 0, s);
+          launch_pool2(cur.data, gn ? ab : nullptr, pl.data, n, S, S, cur.C, s);
+        }
+        cur = pl;
+        S /= 2;
+        ab = nullptr;
+      }
+    }
+    float* pooled = ws->f((size_t)n * cur.C);
+    if (!dry) {
+      ProfScope p(RGFM_KCLASS_OTHER, 0, s);
+      launch_avgpool(cur.data, ab, pooled, n, S * S, cur.C, s);
+      launch_linear_mfma(pooled, h->params + e.fcw, h->params + e.fcb, feat + col0, n, cur.C, F, cur.C, 2 * F, s);
+    }
+  }
+
+  void run(const float* x, const float* y, float* out, int what) {
+    const int F = h->d.feature_dim;
+    float* feat = ws->f((size_t)n * 2 * F);
+    encode(h->ex, x, feat, 0);
+    encode(h->ey, y, feat, F);
+    float* cur = feat;
+    for (const auto& dn : h->hidden) {
+      float* nxt = ws->f((size_t)n * dn.out);
+      if (!dry) {
+        ProfScope p(RGFM_KCLASS_OTHER, 0, s);
+        launch_linear_mfma(cur, h->params + dn.w, h->params + dn.b, nxt, n, dn.in, dn.out, dn.in, dn.out, s);
+        launch_layernorm_silu(nxt, h->params + dn.lw, h->params + dn.lb, n, dn.out, s);
+      }
+      cur = nxt;
+    }
+    if (!dry) {
+      ProfScope p(RGFM_KCLASS_OTHER, 0, s);
+      launch_ratio_head(cur, h->params + h->headw, h->params + h->headb, out, n, h->head_in, h->d.loss_type, what, s);
+    }
+  }
+};
+
+}  // namespace
+
+extern "C" int rgfm_ratio_param_floats(const rgfm_ratio_desc* desc, size_t* n_floats) {
+  int rc = check_ratio_desc(desc);
+  if (rc) return rc;
+  if (!n_floats) return fail(RGFM_EINVAL, "null output");
+  *n_floats = plan_ratio(*desc, nullptr);
+  return RGFM_OK;
+}
+
+extern "C" int rgfm_ratio_create(const rgfm_ratio_desc* desc, const float* params_dev, size_t n_floats,
+                                 rgfm_stream_t stream, rgfm_ratio** out) {
+  int rc = check_ratio_desc(desc);
+  if (rc) return rc;
+  if (!params_dev || !out) return fail(RGFM_EINVAL, "null argument");
+  if ((rc = ensure_init())) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  rgfm_ratio* h = new rgfm_ratio();
+  h->d = *desc;
+  h->n_params = plan_ratio(*desc, h);
+  if (h->n_params != n_floats) {
+    const size_t want = h->n_params;
+    delete h;
+    return fail(RGFM_EINVAL, "parameter blob has %zu floats, architecture needs %zu", n_floats, want);
+  }
+  auto bail = [&](int code, const char* what) {
+    rgfm_ratio_destroy(h);
+    return fail(code, "%s", what);
+  };
+  if (hipMalloc(&h->params, n_floats * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(params)");
+  if (hipMalloc(&h->packed, (h->n_packed + 4) * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(packed)");
+  if (hipMalloc(&h->bn, (h->n_bn + 4) * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(bn)");
+  if (hipMemcpyAsync(h->params, params_dev, n_floats * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return bail(RGFM_EHIP, "hipMemcpyAsync(params)");
+  for (const auto* e : {&h->ex, &h->ey})
+    for (size_t i = 0; i < e->convs.size(); ++i) {
+      const auto& cv = e->convs[i];
+      if (i > 0) launch_pack_conv(h->params + cv.w.w_raw, h->packed + cv.w.w_pk, cv.w.cout, cv.w.cin, 9, nt32_of(cv.w.cout), s);
+      if (desc->kind == RGFM_RATIO_MNIST_SVHN)
+        launch_bn_fold(h->params + cv.nw, h->params + cv.nb, h->params + cv.rm, h->params + cv.rv,
+                       h->bn + cv.bn_scale, h->bn + cv.bn_shift, cv.w.cout, s);
+    }
+  *out = h;
+  return RGFM_OK;
+}
+
+extern "C" void rgfm_ratio_destroy(rgfm_ratio* h) {
+  if (!h) return;
+  if (h->params) (void)hipFree(h->params);
+  if (h->packed) (void)hipFree(h->packed);
+  if (h->bn) (void)hipFree(h->bn);
+  delete h;
+}
+
+extern "C" int rgfm_ratio_workspace_bytes(const rgfm_ratio* h, int n, size_t* bytes) {
+  if (!h || !bytes || n < 1) return fail(RGFM_EINVAL, "bad argument");
+  Bump b;
+  RatioRun r{const_cast<rgfm_ratio*>(h), n, &b, nullptr, true};
+  r.run(nullptr, nullptr, nullptr, 0);
+  *bytes = b.off;
+  return RGFM_OK;
+}
+
+extern "C" int rgfm_ratio_eval(rgfm_ratio* h, const float* x, const float* y, float* out, int n, int what,
+                               void* ws, size_t ws_bytes, rgfm_stream_t stream) {
+  if (!h || !x || !y || !out || !ws) return fail(RGFM_EINVAL, "null argument");
+  if (what < 0 || what > 2) return fail(RGFM_EINVAL, "bad output selector");
+  size_t need = 0;
+  int rc = rgfm_ratio_workspace_bytes(h, n, &need);
+  if (rc) return rc;
+  if (need > ws_bytes) return fail(RGFM_ENOMEM, "workspace too small: %zu < %zu", ws_bytes, need);
+  Bump b;
+  b.base = (char*)ws, b.cap = ws_bytes, b.dry = false;
+  RatioRun r{h, n, &b, (hipStream_t)stream, false};
+  r.run(x, y, out, what);
+  HIP_TRY(hipGetLastError());
+  return RGFM_OK;
+}

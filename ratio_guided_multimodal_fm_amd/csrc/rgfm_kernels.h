@@ -1,0 +1,197 @@
+// rgfm_kernels.h -- internal interface between the C-ABI host code (rgfm_api.cpp)
+// and the gfx950 kernels.  Not part of the public ABI (that is include/rgfm.h).
+//
+// HBM data layout (DESIGN.md "Data layout"):
+//   * boundary tensors (x_t, v, MC set): NCHW fp32, as the reference passes them;
+//   * every internal activation: NHWC fp32  [B][H][W][C]  (channels contiguous:
+//     the implicit-GEMM K axis), produced once and consumed in place -- channel
+//     concat, nearest-upsample, GroupNorm-apply and SiLU are folded into the
+//     consumer's load path, never materialised;
+//   * GroupNorm statistics: per (sample, 64-pixel wave segment, channel) partial
+//     (mean, M2) pairs written by the producer's epilogue:
+//     stats[B][nparts][C][2]; combined (Chan) by gn_finalize into per
+//     (sample, channel) scale/shift  ab[B][C][2].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace rgfm {
+
+constexpr int KC = 16;   // input channels per K-chunk of the MFMA conv
+constexpr int LDP = 20;  // LDS row length (floats) of a 16-channel record: 16 + 4 pad,
+                         // conflict-free for ds_read_b128 (stride 80 B)
+
+// Output tiling of a [B, H, W] raster into 256-pixel workgroup tiles made of
+// four 64-pixel wave segments.
+struct TileGeom {
+  int H, W, HW;
+  int spt;     // samples per tile: 4 when HW <= 64 (one sample per wave segment), else 1
+  int th;      // output rows per tile (spt == 1)
+  int tps;     // tiles per sample (spt == 1)
+  int nparts;  // statistics parts per sample
+};
+
+__host__ __device__ inline TileGeom make_geom(int H, int W) {
+  TileGeom g;
+  g.H = H;
+  g.W = W;
+  g.HW = H * W;
+  if (g.HW <= 64) {
+    g.spt = 4;
+    g.th = H;
+    g.tps = 1;
+    g.nparts = 1;
+  } else {
+    g.spt = 1;
+    const int thmax = 256 / W;
+    const int nt = (H + thmax - 1) / thmax;
+    g.th = (H + nt - 1) / nt;
+    g.tps = nt;
+    g.nparts = nt * 4;
+  }
+  return g;
+}
+
+__host__ __device__ inline int geom_num_tiles(const TileGeom& g, int B) {
+  return g.spt == 1 ? B * g.tps : (B + g.spt - 1) / g.spt;
+}
+
+// valid pixels of statistics part `part` of a sample
+__host__ __device__ inline int geom_part_count(const TileGeom& g, int part) {
+  if (g.spt != 1) return g.HW;
+  const int tile = part >> 2, w = part & 3;
+  int rows = g.H - tile * g.th;
+  if (rows > g.th) rows = g.th;
+  int n = rows * g.W - 64 * w;
+  return n < 0 ? 0 : (n > 64 ? 64 : n);
+}
+
+enum ConvMode { CONV_S1 = 0, CONV_S2 = 1, CONV_UP2 = 2 };
+
+struct ConvArgs {
+  // input: up to two NHWC sources concatenated along C (torch.cat([h, skip], 1))
+  const float* in0;
+  const float* in1;
+  int C0, C1;        // channels of in0 / in1 (C1 = 0: single source)
+  int Hin, Win;      // spatial size of the sources
+  const float* ab;   // [B][C0+C1][2] GroupNorm scale/shift (then SiLU) applied on load; null = raw
+  const float* wpk;  // packed 3x3 weights  [Cout/(32NT)][Cin/16][9][32NT][16]
+  const float* bias; // [Cout]
+  const float* temb; // time-embedding add: temb[(per_row ? b : 0) * temb_stride + c]; null = none
+  int temb_stride;
+  int temb_per_row;
+  // residual: res_mode 0 none; 1 identity (res0 NHWC [.., Cout]); 2 fused 1x1 conv over cat(res0, res1)
+  int res_mode;
+  const float* res0;
+  const float* res1;
+  int R0, R1;
+  const float* wskip;      // packed 1x1 weights [Cout/(32NT)][(R0+R1)/16][1][32NT][16]
+  const float* skip_bias;  // [Cout]
+  // epilogue activation (ratio-net BatchNorm folded to scale/shift, then SiLU); null = none
+  const float* ep_scale;
+  const float* ep_shift;
+  float* out;        // NHWC [B][H][W][Cout]
+  float* stats_out;  // [B][nparts][Cout][2] or null
+  int B, Cout;
+  TileGeom g;        // OUTPUT raster tiling
+  int halo_px;       // pixels of the staged input tile
+};
+
+struct ConvInArgs {  // first conv of a net: NCHW image -> NHWC features
+  const float* x;    // [B][CIN][H][W]
+  const float* w;    // [C0][CIN][3][3] (reference layout)
+  const float* bias;
+  const float* ep_scale;  // optional BatchNorm scale/shift + SiLU epilogue (ratio nets)
+  const float* ep_shift;
+  float* out;        // NHWC [B][H][W][C0]
+  float* stats_out;  // or null
+  int B, C0;
+  TileGeom g;
+};
+
+struct ConvOutArgs {  // out_conv(silu(out_norm(h))) -> NCHW velocity, optional fused Euler
+  const float* in;    // NHWC [B][H][W][Cin]
+  const float* ab;    // [B][Cin][2]
+  const float* w;     // [CIMG][Cin][3][3] (reference layout)
+  const float* bias;
+  float* v_out;       // NCHW velocity or null
+  float* x_state;     // NCHW state for the fused Euler update or null
+  float dt;
+  int B, Cin;
+  TileGeom g;
+  int halo_px;
+};
+
+struct GnFinalizeArgs {
+  const float* stats0;  // [B][nparts][C0][2]
+  const float* stats1;  // [B][nparts][C1][2] or null
+  int C0, C1, groups;
+  const float* gamma;   // [C0+C1]
+  const float* beta;
+  float* ab;            // [B][C0+C1][2]
+  int B;
+  TileGeom g;
+};
+
+struct TimeLinear {  // one ResBlock time_mlp Linear: rows [out_off, out_off+cout) of the table
+  int w_off, b_off, cout, out_off;
+};
+
+struct TimeEmbedArgs {
+  const float* params;     // state_dict-order blob (device copy)
+  const float* freqs;      // [mc/2]
+  int mc, temb;
+  int te0w, te0b, te2w, te2b;  // offsets into params
+  const TimeLinear* lin;   // device array
+  int nlin;
+  int total;               // table row length
+  // time values: either explicit t_dev[nt] or step index based: t = (float)((step_begin + i) * (1.0/num_steps))
+  const float* t_dev;
+  int num_steps, step_begin;
+  float* table;            // [nt][total]
+};
+
+void launch_conv_mfma(const ConvArgs& a, int mode, hipStream_t s);
+size_t conv_mfma_lds_bytes(const ConvArgs& a);
+int conv_mfma_init();  // raises the dynamic-LDS limit of every instantiation
+
+void launch_conv_in(const ConvInArgs& a, int cin, hipStream_t s);
+void launch_conv_out(const ConvOutArgs& a, int cimg, hipStream_t s);
+void launch_gn_finalize(const GnFinalizeArgs& a, hipStream_t s);
+void launch_time_embed(const TimeEmbedArgs& a, int nt, hipStream_t s);
+void launch_pack_conv(const float* w, float* out, int Cout, int Cin, int taps, int nt32, hipStream_t s);
+void launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, hipStream_t s);
+
+// ---- ratio-estimator helpers
+void launch_pool2(const float* in, const float* ab, float* out, int B, int H, int W, int C, hipStream_t s);
+void launch_avgpool(const float* in, const float* ab, float* out, int B, int HW, int C, hipStream_t s);
+void launch_linear_mfma(const float* x, const float* w, const float* b, float* y, int rows, int in,
+                        int out, int x_stride, int y_stride, hipStream_t s);
+void launch_layernorm_silu(float* x, const float* w, const float* b, int rows, int n, hipStream_t s);
+void launch_ratio_head(const float* x, const float* w, const float* b, float* out, int rows, int n,
+                       int loss, int what, hipStream_t s);
+void launch_bn_fold(const float* w, const float* b, const float* rm, const float* rv, float* scale,
+                    float* shift, int C, hipStream_t s);
+
+// ---- guidance / Euler
+struct GuidanceArgs {
+  const float* x;  // [B][dx]
+  const float* y;  // [B][dy]
+  float* vx;       // in: model velocity, out: blended velocity (when x_state null)
+  float* vy;
+  const float* mc_x1;
+  const float* mc_y1;
+  const float* mc_ratios;
+  int B, N, dx, dy;
+  float tf, s2, cden, g1, g2;
+  float* logp;         // [B][N] scratch
+  float* weights_out;  // optional [B][N]
+  float* x_state;      // optional fused Euler: x_state += dt * blended
+  float* y_state;
+  float dt;
+};
+void launch_guidance(const GuidanceArgs& a, hipStream_t s);
+void launch_euler(float* x, const float* v, size_t n, float dt, hipStream_t s);
+
+}  // namespace rgfm

@@ -1,0 +1,360 @@
+// unet_kernels.hip -- the non-GEMM kernels of a U-Net evaluation: first conv
+// (NCHW image -> NHWC features), output head (+ fused Euler update), GroupNorm
+// statistics finalisation, time-embedding MLP, weight packing, layout helpers.
+// All are HBM/latency-bound; none is reshaped into a GEMM.
+#include "rgfm_device.h"
+
+namespace rgfm {
+
+// ------------------------------------------------------------------ conv_in
+// input_conv (src/models/unet_flexible.py:155, :219) and the first conv of the
+// ratio encoders (src/models/ratio_flexible.py:195/:245, ratio_estimator.py:46).
+// Workgroup = one 256-pixel tile; wave = one 64-pixel segment; lane = output
+// channel (lane & 31) x pixel parity (lane >> 5).  The image halo is read from
+// LDS as wave-uniform broadcasts; the 9*CIN weights of a channel sit in registers.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_in_kernel(const ConvInArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const TileGeom g = a.g;
+  const int W = g.W, H = g.H, HW = g.HW;
+  int b0, row0;
+  if (g.spt == 1) {
+    b0 = blockIdx.x / g.tps;
+    row0 = (blockIdx.x - b0 * g.tps) * g.th;
+  } else {
+    b0 = blockIdx.x * g.spt;
+    row0 = 0;
+  }
+  const int HR = g.th + 2, WR = W + 2, per = HR * WR;
+  int rows_valid = H - row0;
+  if (rows_valid > g.th) rows_valid = g.th;
+  const int nvalid = rows_valid * W;
+
+  // stage zero-padded image halo: smem[(s*CIN + ci)*per + hy*WR + hx]
+  for (int it = tid; it < g.spt * CIN * per; it += 256) {
+    const int sc = it / per, rem = it - sc * per;
+    const int s = sc / CIN, ci = sc - s * CIN;
+    const int hy = rem / WR, hx = rem - hy * WR;
+    const int y = row0 + hy - 1, x = hx - 1, b = b0 + s;
+    float v = 0.f;
+    if (y >= 0 && y < H && x >= 0 && x < W && b < a.B) v = a.x[((size_t)(b * CIN + ci) * H + y) * W + x];
+    smem[it] = v;
+  }
+  __syncthreads();
+
+  const int bw = (g.spt == 1) ? b0 : b0 + wave;
+  const bool sample_ok = bw < a.B;
+  const int sidx = (g.spt == 1) ? 0 : wave;
+  // pixel k of this lane: segment pixel pl = 2k + h
+  int nw;
+  if (g.spt == 1) {
+    nw = nvalid - 64 * wave;
+    nw = nw < 0 ? 0 : (nw > 64 ? 64 : nw);
+  } else {
+    nw = sample_ok ? HW : 0;
+  }
+  const size_t pix0 = (g.spt == 1) ? (size_t)b0 * HW + (size_t)row0 * W + 64 * wave : (size_t)bw * HW;
+  const int part = (g.spt == 1) ? (blockIdx.x - b0 * g.tps) * 4 + wave : 0;
+
+  for (int cg = 0; cg < a.C0 / 32; ++cg) {
+    const int c = cg * 32 + l31;
+    float wr[CIN * 9];
+#pragma unroll
+    for (int i = 0; i < CIN * 9; ++i) wr[i] = a.w[(size_t)c * CIN * 9 + i];
+    const float bias = a.bias[c];
+    const float es = a.ep_scale ? a.ep_scale[c] : 1.f, eh = a.ep_scale ? a.ep_shift[c] : 0.f;
+    float vals[32];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      const int pl = 2 * k + h;
+      const bool valid = pl < nw;
+      const int q = valid ? ((g.spt == 1) ? 64 * wave + pl : pl) : 0;
+      const int r = q / W, x = q - r * W;
+      const float* base = smem + sidx * CIN * per + r * WR + x;
+      float acc = bias;
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) acc += wr[ci * 9 + ky * 3 + kx] * base[ci * per + ky * WR + kx];
+      if (a.ep_scale) acc = silu_f(acc * es + eh);
+      vals[k] = valid ? acc : 0.f;
+      sum += vals[k];
+      if (valid) a.out[(pix0 + pl) * a.C0 + c] = acc;
+    }
+    if (a.stats_out) {
+      sum += __shfl_xor(sum, 32);
+      const float mean = nw > 0 ? sum / (float)nw : 0.f;
+      float m2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 32; ++k)
+        if (2 * k + h < nw) {
+          const float d = vals[k] - mean;
+          m2 += d * d;
+        }
+      m2 += __shfl_xor(m2, 32);
+      if (h == 0 && sample_ok) {
+        float2 st;
+        st.x = mean, st.y = m2;
+        *reinterpret_cast<float2*>(a.stats_out + (((size_t)bw * g.nparts + part) * a.C0 + c) * 2) = st;
+      }
+    }
+  }
+}
+
+void launch_conv_in(const ConvInArgs& a, int cin, hipStream_t s) {
+  const int per = (a.g.th + 2) * (a.g.W + 2);
+  const size_t lds = (size_t)a.g.spt * cin * per * sizeof(float);
+  dim3 grid(geom_num_tiles(a.g, a.B));
+  if (cin == 1) hipLaunchKernelGGL(conv_in_kernel<1>, grid, dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(conv_in_kernel<3>, grid, dim3(256), lds, s, a);
+}
+
+// ------------------------------------------------------------------ conv_out
+// out_conv(silu(out_norm(h))) (src/models/unet_flexible.py:257-259) with the Euler
+// update x <- x + v*dt (src/sample_mnist_svhn.py:174-175) optionally fused.
+// thread = output pixel; the transformed input chunk is staged in LDS exactly as
+// in conv_mfma; the weights are wave-uniform (scalar loads).
+template <int CIMG>
+__global__ __launch_bounds__(256) void conv_out_kernel(const ConvOutArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const TileGeom g = a.g;
+  const int W = g.W, H = g.H, HW = g.HW;
+  int b0, row0;
+  if (g.spt == 1) {
+    b0 = blockIdx.x / g.tps;
+    row0 = (blockIdx.x - b0 * g.tps) * g.th;
+  } else {
+    b0 = blockIdx.x * g.spt;
+    row0 = 0;
+  }
+  const int HR = g.th + 2, WR = W + 2;
+  int rows_valid = H - row0;
+  if (rows_valid > g.th) rows_valid = g.th;
+  const int nvalid = rows_valid * W;
+
+  const int p = tid;
+  int s, q;
+  bool valid;
+  if (g.spt == 1) {
+    s = 0;
+    valid = p < nvalid;
+    q = valid ? p : 0;
+  } else {
+    s = p >> 6;
+    valid = ((p & 63) < HW) && (b0 + s < a.B);
+    q = (p & 63) < HW ? (p & 63) : 0;
+  }
+  const int r = q / W, x = q - r * W;
+  const int abase = ((s * HR + r) * WR + x) * LDP;
+
+  float acc[CIMG];
+#pragma unroll
+  for (int co = 0; co < CIMG; ++co) acc[co] = 0.f;
+
+  for (int ch = 0; ch < a.Cin / KC; ++ch) {
+    __syncthreads();
+    stage_input<CONV_S1>(smem, a.in, nullptr, a.Cin, 0, H, W, a.ab, ch * KC, a.B, b0, row0, H, W, HR,
+                         WR, a.halo_px, tid, 256);
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      const float* ap = smem + abase + (ky * WR + kx) * LDP;
+      float v[KC];
+#pragma unroll
+      for (int j = 0; j < KC / 4; ++j) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(ap + 4 * j);
+        v[4 * j] = t.x, v[4 * j + 1] = t.y, v[4 * j + 2] = t.z, v[4 * j + 3] = t.w;
+      }
+#pragma unroll
+      for (int co = 0; co < CIMG; ++co)
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk)
+          acc[co] += v[kk] * a.w[((size_t)co * a.Cin + ch * KC + kk) * 9 + tap];
+    }
+  }
+  if (!valid) return;
+  const int b = b0 + s;
+  const int pixl = (g.spt == 1) ? row0 * W + p : (p & 63);
+#pragma unroll
+  for (int co = 0; co < CIMG; ++co) {
+    const float v = acc[co] + a.bias[co];
+    const size_t idx = ((size_t)b * CIMG + co) * HW + pixl;
+    if (a.v_out) a.v_out[idx] = v;
+    if (a.x_state) a.x_state[idx] = __fadd_rn(a.x_state[idx], __fmul_rn(v, a.dt));
+  }
+}
+
+void launch_conv_out(const ConvOutArgs& a, int cimg, hipStream_t s) {
+  const size_t lds = (size_t)a.halo_px * LDP * sizeof(float);
+  dim3 grid(geom_num_tiles(a.g, a.B));
+  if (cimg == 1) hipLaunchKernelGGL(conv_out_kernel<1>, grid, dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(conv_out_kernel<3>, grid, dim3(256), lds, s, a);
+}
+
+// ------------------------------------------------------------------ gn_finalize
+// nn.GroupNorm statistics (src/models/unet_flexible.py:51,61,196): combine the
+// producers' per-(segment, channel) (mean, M2) partials with Chan's parallel
+// formula (fp64, fixed order => deterministic), then emit per-(sample, channel)
+//   a = rstd * gamma,  b = beta - mean * a      so that  GN(x) = a*x + b.
+// One workgroup per sample; thread = channel of the (possibly concatenated) input.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const GnFinalizeArgs a) {
+  __shared__ double s_mean[512], s_m2[512];
+  __shared__ float s_gm[32], s_rstd[32];
+  const int b = blockIdx.x;
+  const int C = a.C0 + a.C1;
+  const TileGeom g = a.g;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float* st;
+    int cs, cc;
+    if (c < a.C0) {
+      st = a.stats0, cs = a.C0, cc = c;
+    } else {
+      st = a.stats1, cs = a.C1, cc = c - a.C0;
+    }
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int p = 0; p < g.nparts; ++p) {
+      const int np = geom_part_count(g, p);
+      if (np == 0) continue;
+      const float2 v = *reinterpret_cast<const float2*>(st + (((size_t)b * g.nparts + p) * cs + cc) * 2);
+      const double nb = (double)np, d = (double)v.x - mean, nn = n + nb;
+      mean += d * nb / nn;
+      m2 += (double)v.y + d * d * n * nb / nn;
+      n = nn;
+    }
+    s_mean[c] = mean;
+    s_m2[c] = m2;
+  }
+  __syncthreads();
+  const int cpg = C / a.groups;
+  if ((int)threadIdx.x < a.groups) {
+    const int gi = threadIdx.x;
+    double gm = 0.0;
+    for (int j = 0; j < cpg; ++j) gm += s_mean[gi * cpg + j];
+    gm /= (double)cpg;
+    double m2 = 0.0;
+    for (int j = 0; j < cpg; ++j) {
+      const double d = s_mean[gi * cpg + j] - gm;
+      m2 += s_m2[gi * cpg + j] + d * d * (double)g.HW;
+    }
+    const double var = m2 / ((double)cpg * (double)g.HW);
+    s_gm[gi] = (float)gm;
+    s_rstd[gi] = (float)(1.0 / sqrt(var + 1e-5));
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int gi = c / cpg;
+    const float sc = s_rstd[gi] * a.gamma[c];
+    float2 o;
+    o.x = sc;
+    o.y = a.beta[c] - s_gm[gi] * sc;
+    *reinterpret_cast<float2*>(a.ab + ((size_t)b * C + c) * 2) = o;
+  }
+}
+
+void launch_gn_finalize(const GnFinalizeArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.B), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------ time embedding
+// timestep_embedding + time_embed MLP (src/models/unet_flexible.py:16-36, :148-152,
+// :215-216) + every ResBlock's time_mlp = Linear(SiLU(t_emb)) (:55-58, :77).
+// One workgroup per time value; each wave computes dot products with lane-strided
+// (coalesced) weight reads and a shuffle reduction.  Inside the samplers t depends
+// only on the step index, so the whole [steps][total] table is built once per call.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void time_embed_kernel(const TimeEmbedArgs a) {
+  __shared__ float s_emb[256], s_h[1024], s_st[1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = blockIdx.x;
+  float t;
+  if (a.t_dev) t = a.t_dev[i];
+  else t = (float)((double)(a.step_begin + i) * (1.0 / (double)a.num_steps));
+  const int half = a.mc / 2;
+  if (tid < half) {
+    const float arg = t * a.freqs[tid];
+    s_emb[tid] = cosf(arg);
+    s_emb[half + tid] = sinf(arg);
+  }
+  __syncthreads();
+  const float* P = a.params;
+  for (int o = wave; o < a.temb; o += 4) {
+    float acc = 0.f;
+    for (int k = lane; k < a.mc; k += 64) acc += P[a.te0w + (size_t)o * a.mc + k] * s_emb[k];
+    acc = wave_sum(acc);
+    if (lane == 0) s_h[o] = silu_f(acc + P[a.te0b + o]);
+  }
+  __syncthreads();
+  for (int o = wave; o < a.temb; o += 4) {
+    float acc = 0.f;
+    for (int k = lane; k < a.temb; k += 64) acc += P[a.te2w + (size_t)o * a.temb + k] * s_h[k];
+    acc = wave_sum(acc);
+    if (lane == 0) s_st[o] = silu_f(acc + P[a.te2b + o]);  // SiLU of time_mlp
+  }
+  __syncthreads();
+  for (int li = 0; li < a.nlin; ++li) {
+    const TimeLinear L = a.lin[li];
+    for (int o = wave; o < L.cout; o += 4) {
+      float acc = 0.f;
+      for (int k = lane; k < a.temb; k += 64) acc += P[L.w_off + (size_t)o * a.temb + k] * s_st[k];
+      acc = wave_sum(acc);
+      if (lane == 0) a.table[(size_t)i * a.total + L.out_off + o] = acc + P[L.b_off + o];
+    }
+  }
+}
+
+void launch_time_embed(const TimeEmbedArgs& a, int nt, hipStream_t s) {
+  hipLaunchKernelGGL(time_embed_kernel, dim3(nt), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------ weight packing
+// [Cout][Cin][taps] (reference Conv2d layout) -> [Cout/nb][Cin/16][taps][nb][16], nb = 32*nt32
+__global__ void pack_conv_kernel(const float* w, float* out, int Cout, int Cin, int taps, int nb) {
+  const size_t total = (size_t)Cout * Cin * taps;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int kk = i % 16;
+    size_t r = i / 16;
+    const int n = r % nb;
+    r /= nb;
+    const int tap = r % taps;
+    r /= taps;
+    const int nch = Cin / 16;
+    const int ch = r % nch;
+    const int blk = r / nch;
+    const int co = blk * nb + n, ci = ch * 16 + kk;
+    out[i] = w[((size_t)co * Cin + ci) * taps + tap];
+  }
+}
+
+void launch_pack_conv(const float* w, float* out, int Cout, int Cin, int taps, int nt32, hipStream_t s) {
+  hipLaunchKernelGGL(pack_conv_kernel, dim3(256), dim3(256), 0, s, w, out, Cout, Cin, taps, 32 * nt32);
+}
+
+// ------------------------------------------------------------------ layout helper (parity hook)
+__global__ void nhwc_to_nchw_kernel(const float* in, float* out, int B, int C, int HW) {
+  const size_t total = (size_t)B * C * HW;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int p = i % HW;
+    const size_t r = i / HW;
+    const int c = r % C;
+    const size_t b = r / C;
+    out[i] = in[(b * HW + p) * C + c];
+  }
+}
+
+void launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, hipStream_t s) {
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(512), dim3(256), 0, s, in, out, B, C, HW);
+}
+
+}  // namespace rgfm
