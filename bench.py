@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Headline benchmark: paired images/sec of the ratio-guided sampler
+(MNIST32 1x32x32 + SVHN 3x32x32, mc_feng guidance 0.5, 100 Euler steps,
+N_mc = 256, batch 512 PER GPU) -- BASELINE.json configs[2] at 1 GPU, configs[3]
+at 8 GPUs (weak scaling, 512 rows per rank).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one whole sampling call: sharded MC pre-phase + ratio estimator +
+all_gather of the MC set + the guided Euler loop + the gather of the outputs,
+on noise that is already resident in HBM.  Synthetic parameters
+(ratio_guided_multimodal_fm_amd/synth.py, no trained checkpoint exists) and
+CPU-generator noise seeded 42 (the reference CLI's default seed).
+
+Rank 0 prints ONE JSON line with the driver's contract fields plus
+  roofline     : fp32-MFMA conv kernel class, hipEvent-timed on the launch stream
+                 inside the timed region (librgfm_hip's rgfm_profile_*)
+  cpu_baseline : the CPU oracle (a C port of the reference algorithm, test
+                 infrastructure) timed on this host's cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--batch-per-gpu", type=int, default=512)
+    p.add_argument("--mc", type=int, default=256)
+    p.add_argument("--euler-steps", type=int, default=100)
+    p.add_argument("--gamma", type=float, default=0.5)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-kernel-timers", action="store_true",
+                   help="skip the hipEvent kernel-class timers (use under rocprofv3)")
+    return p.parse_args()
+
+
+def cpu_baseline(fm, fs, rr, euler_steps, B_full, N_full):
+    """Oracle timing on a bounded sample of the same workload (reported, not the target)."""
+    from oracle import oracle as O
+    from ratio_guided_multimodal_fm_amd.synth import paired_noise
+    cores = O.num_threads()
+    B, N, S = max(16, cores), max(8, cores // 2), 12  # one row per core: the oracle threads over rows
+    noise = tuple(v.numpy() for v in paired_noise(42, B, N, (1, 32, 32), (3, 32, 32)))
+    dx, bx, dy, by, br = O.desc_of(fm), O.blob_of(fm), O.desc_of(fs), O.blob_of(fs), O.blob_of(rr)
+    t0 = time.perf_counter()
+    # first S of `euler_steps` Euler steps of the MC pre-phase, the ratio net, and the guided loop
+    mx = O.sample_single(dx, bx, noise[2], euler_steps, 0, S)
+    my = O.sample_single(dy, by, noise[3], euler_steps, 0, S)
+    r = O.ratio_eval("mnist_svhn", br, mx, my, "ratio", "disc")
+    O.sample_pair(dx, bx, dy, by, noise[0], noise[1], mx, my, r, euler_steps, 0.5, 0, S)
+    dt = time.perf_counter() - t0
+    row_steps = (B + N) * S                      # U-Net pair evaluations done (>99.9 % of the work)
+    full = (B_full + N_full) * euler_steps       # pair evaluations of one full call
+    return {
+        "value": B_full / (dt * full / row_steps),
+        "unit": "paired images/sec",
+        "cores": O.num_threads(),
+        "kind": "port",
+        "sample": f"B={B}, N_mc={N}, {S} of {euler_steps} Euler steps (pre-phase + ratio + guided loop) "
+                  f"= {row_steps} U-Net pair evaluations in {dt:.1f} s, scaled to the {full} of one full call",
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from ratio_guided_multimodal_fm_amd import _engine, models as M
+    from ratio_guided_multimodal_fm_amd.distributed import sharded_paired_sampler
+    from ratio_guided_multimodal_fm_amd.synth import load_synth, paired_noise
+
+    fm = load_synth(M.FlowMatchingUNetMNIST(32), 0).eval()
+    fs = load_synth(M.FlowMatchingUNetSVHN(), 1).eval()
+    rr = load_synth(M.RatioEstimatorMNISTSVHN(), 2).eval()
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(fm, fs, rr, args.euler_steps, args.batch_per_gpu, args.mc)
+    fm, fs, rr = fm.to(dev), fs.to(dev), rr.to(dev)
+
+    B = args.batch_per_gpu * world
+    # host noise (reference draw order), identical on every rank; one device-resident copy per call
+    x0, y0, mx0, my0 = paired_noise(42, B, args.mc, (1, 32, 32), (3, 32, 32))
+    calls = args.warmup + args.steps
+    resident = [tuple(t.to(dev) for t in (x0, y0, mx0, my0)) for _ in range(calls)]
+    torch.cuda.synchronize()
+
+    def one_call(i):
+        return sharded_paired_sampler(fm, fs, rr, "mc_feng", args.gamma, args.euler_steps, resident[i], dev,
+                                      gather="rank0")
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_call(i)
+    timers = not args.no_kernel_timers
+    fence()
+    if timers:
+        _engine.profile(enable=True, reset=True)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, calls):
+        out = one_call(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    conv_ms = conv_n = conv_fl = 0.0
+    if timers:
+        conv_ms, conv_n, conv_fl = _engine.profile_read(0)
+        _engine.profile(enable=False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        assert out[0] is not None and out[0].shape[0] == B and torch.isfinite(out[0]).all()
+        value = B * args.steps / elapsed
+        line = {
+            "metric": "paired images/sec (MNIST32+SVHN, 100 Euler steps)",
+            "value": value,
+            "unit": "paired images/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "MNIST32 (1x32x32) + SVHN (3x32x32) pair, mc_feng guidance "
+                            f"{args.gamma}, {args.euler_steps} Euler steps, N_mc={args.mc}, "
+                            f"batch {args.batch_per_gpu} per GPU (BASELINE configs[2]; configs[3] at 8 GPUs)",
+                "global_batch": B,
+                "parallelism": f"rows sharded over {world} rank(s); all_gather(MC set) + gather(outputs)",
+                "step": "one full sampling call (MC pre-phase + ratio + guided Euler loop + gather)",
+            },
+        }
+        if timers and conv_ms > 0:
+            ach = conv_fl / (conv_ms * 1e-3) / 1e12
+            line["roofline"] = {
+                "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                "kernel": "conv_mfma_kernel (fp32 MFMA implicit-GEMM conv, all shapes)",
+                "launches": int(conv_n), "avg_launch_us": 1e3 * conv_ms / max(conv_n, 1),
+                "kernel_time_share": conv_ms * 1e-3 / elapsed,
+            }
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,125 @@
+"""Multi-GPU sampler: one process per GPU, rows sharded, RCCL over xGMI.
+
+New design (the reference has no multi-device code).  Rows of (x_t, y_t) never
+interact -- per-sample GroupNorm, eval-mode BatchNorm, and guidance weights that
+depend only on the row and the SHARED Monte-Carlo set
+(reference src/sample_mnist_svhn.py:130-167) -- so:
+
+  1. the MC pre-phase (sample_mnist_svhn.py:85-104) is sharded too: rank r
+     integrates rows [r*N/W, (r+1)*N/W) of mc_x0 / mc_y0 and evaluates the
+     ratio estimator on them;
+  2. ONE all_gather of (mc_x1, mc_y1, mc_ratios) makes the MC set identical
+     on every rank (N*(Dx+Dy+1)*4 bytes, 4.2 MB at N=256: latency-bound);
+  3. each rank runs the guided Euler loop on its rows of (x0, y0);
+  4. ONE gather (or all_gather) of the outputs.
+
+No collective sits inside the Euler loop.  `backend` abstracts the three compute
+calls so that the sharding logic can be exercised with gloo on CPU ranks (the
+tests inject the CPU oracle there); the default backend is the HIP library.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n, world, rank):
+    """Contiguous shard [lo, hi) of n rows; the first n % world ranks get one extra."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+class HipBackend:
+    """Compute calls routed to librgfm_hip.so (the product path)."""
+
+    def sample_single(self, model, x, num_steps):
+        from . import _engine
+        return _engine.sample_single(model, x, num_steps)
+
+    def ratios(self, ratio_estimator, mc_x1, mc_y1):
+        return ratio_estimator._engine.eval(mc_x1, mc_y1, "ratio")
+
+    def sample_pair(self, fm_x, fm_y, x, y, mc_x1, mc_y1, mc_ratios, num_steps, gamma):
+        from . import _engine
+        return _engine.sample_pair(fm_x, fm_y, x, y, mc_x1, mc_y1, mc_ratios, num_steps, gamma)
+
+
+def _all_gather_rows(t, counts, group):
+    """all_gather of row-sharded tensors with possibly unequal row counts."""
+    world = len(counts)
+    if world == 1:
+        return t
+    mx = max(counts)
+    if t.shape[0] < mx:
+        pad = torch.zeros((mx - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        t = torch.cat([t, pad], 0)
+    t = t.contiguous()
+    if all(c == mx for c in counts):
+        out = torch.empty((world * mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t, group=group)
+        return out
+    bufs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(bufs, t, group=group)
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0)
+
+
+def sharded_paired_sampler(fm_x, fm_y, ratio_estimator, guidance_method, guidance_strength, num_steps,
+                           noise, device, backend=None, group=None, gather="rank0"):
+    """Sharded equivalent of ``paired_sampler`` on explicit host noise.
+
+    noise = (x0, y0, mc_x0, mc_y0): the FULL tensors, identical on every rank
+    (every rank regenerates them from the seed; each slices its own rows).
+    Returns (x, y) with all rows: on every rank for gather="all", on rank 0
+    only (None, None elsewhere) for gather="rank0".
+    """
+    backend = backend or HipBackend()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    x0, y0, mc_x0, mc_y0 = noise
+    B = x0.shape[0]
+    guided = guidance_method == 'mc_feng' and ratio_estimator is not None
+    for m in (fm_x, fm_y, ratio_estimator):
+        if m is not None:
+            m.eval()
+
+    mc_x1 = mc_y1 = mc_r = None
+    if guided:
+        N = mc_x0.shape[0]
+        lo, hi = shard_bounds(N, world, rank)
+        sx = mc_x0[lo:hi].to(device).contiguous()
+        sy = mc_y0[lo:hi].to(device).contiguous()
+        if hi > lo:
+            backend.sample_single(fm_x, sx, num_steps)
+            backend.sample_single(fm_y, sy, num_steps)
+            sr = backend.ratios(ratio_estimator, sx, sy)
+        else:
+            sr = torch.empty(0, device=device)
+        counts = [shard_bounds(N, world, r)[1] - shard_bounds(N, world, r)[0] for r in range(world)]
+        mc_x1 = _all_gather_rows(sx, counts, group)
+        mc_y1 = _all_gather_rows(sy, counts, group)
+        mc_r = _all_gather_rows(sr, counts, group)
+
+    lo, hi = shard_bounds(B, world, rank)
+    x = x0[lo:hi].to(device).contiguous()
+    y = y0[lo:hi].to(device).contiguous()
+    if hi > lo:
+        backend.sample_pair(fm_x, fm_y, x, y, mc_x1, mc_y1, mc_r, num_steps, guidance_strength)
+    if world == 1:
+        return x, y
+    counts = [shard_bounds(B, world, r)[1] - shard_bounds(B, world, r)[0] for r in range(world)]
+    if gather == "all":
+        return _all_gather_rows(x, counts, group), _all_gather_rows(y, counts, group)
+    return _gather_rows(x, counts, group, rank), _gather_rows(y, counts, group, rank)
+
+
+def _gather_rows(t, counts, group, rank, dst=0):
+    world = len(counts)
+    mx = max(counts)
+    if t.shape[0] < mx:
+        pad = torch.zeros((mx - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        t = torch.cat([t, pad], 0)
+    t = t.contiguous()
+    bufs = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
+    dist.gather(t, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0)
