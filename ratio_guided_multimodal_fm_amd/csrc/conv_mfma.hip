@@ -69,13 +69,40 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) bbase[nt] = (nt * 32 + l31) * LDP + h * 8;
 
+  // Accumulators start from bias (+ skip bias) + time embedding (+ identity residual):
+  // the residual tile is fetched while the first K-chunk is being staged instead of in a
+  // serial epilogue tail.  D layout: column (channel) = lane & 31,
+  // row (pixel) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+  const int bw = (g.spt == 1) ? b0 : b0 + wave;  // sample of this wave's segment
+  const bool sample_ok = bw < a.B;
+  const size_t pix0 = (g.spt == 1) ? (size_t)b0 * HW + (size_t)row0 * W : (size_t)bw * HW;
   f32x16 acc[2][NT];
+  {
+    float add0[NT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+    for (int nt = 0; nt < NT; ++nt) {
+      const int c = n0 + nt * 32 + l31;
+      float v = a.bias[c];
+      if (a.res_mode == 2) v += a.skip_bias[c];
+      if (a.temb && sample_ok) v += a.temb[(size_t)(a.temb_per_row ? bw : 0) * a.temb_stride + c];
+      add0[nt] = v;
+    }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        const int pl = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int p = 64 * wave + pl;
+        const bool valid = (g.spt == 1) ? (p < nvalid) : (sample_ok && pl < HW);
+        const size_t pix = pix0 + ((g.spt == 1) ? p : pl);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          float v = add0[nt];
+          if (a.res_mode == 1 && valid) v += a.res0[pix * a.Cout + n0 + nt * 32 + l31];
+          acc[mt][nt][r] = v;
+        }
+      }
+  }
 
   const int cin = a.C0 + a.C1;
   const int nch_main = cin / KC;
@@ -137,21 +164,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   }
 
   // ---------------------------------------------------------------- epilogue
-  // D layout: column (channel) = lane & 31, row (pixel) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
-  const int bw = (g.spt == 1) ? b0 : b0 + wave;  // sample of this wave's segment
-  const bool sample_ok = bw < a.B;
-  float addb[NT], addt[NT], eps_[NT], eph_[NT];
+  float eps_[NT], eph_[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int c = n0 + nt * 32 + l31;
-    addb[nt] = a.bias[c];
-    if (a.res_mode == 2) addb[nt] += a.skip_bias[c];
-    addt[nt] = 0.f;
-    if (a.temb && sample_ok) addt[nt] = a.temb[(size_t)(a.temb_per_row ? bw : 0) * a.temb_stride + c];
     eps_[nt] = a.ep_scale ? a.ep_scale[c] : 1.f;
     eph_[nt] = a.ep_scale ? a.ep_shift[c] : 0.f;
   }
-  const size_t pix0 = (g.spt == 1) ? (size_t)b0 * HW + (size_t)row0 * W : (size_t)bw * HW;
   unsigned vmask[2] = {0u, 0u};
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
@@ -165,8 +184,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int c = n0 + nt * 32 + l31;
-        float v = (acc[mt][nt][r] + addb[nt]) + addt[nt];
-        if (a.res_mode == 1 && valid) v += a.res0[pix * a.Cout + c];
+        float v = acc[mt][nt][r];
         if (a.ep_scale) v = silu_f(v * eps_[nt] + eph_[nt]);
         acc[mt][nt][r] = v;
         if (valid) a.out[pix * a.Cout + c] = v;

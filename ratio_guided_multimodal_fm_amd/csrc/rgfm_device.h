@@ -9,6 +9,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
 
+// SiLU on the conv load path: v_exp_f32 + v_rcp_f32 (each ~1 ulp) instead of the
+// IEEE expf / division sequences (~25 VALU instructions per element, which the
+// staging of every K-chunk pays 28 times per thread).  |rel err| < 3e-7.
+__device__ __forceinline__ float silu_fast(float v) {
+  const float e = __builtin_amdgcn_exp2f(v * -1.44269504088896341f);
+  return v * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
 // Stage the input halo tile of channel chunk `c` (16 channels starting at concat
 // channel c) into sA[halo_px][LDP].  Shared with conv_out.
 template <int MODE>
@@ -55,10 +63,10 @@ __device__ __forceinline__ void stage_input(float* sA, const float* in0, const f
       if (ab) {
         const f32x4* p = reinterpret_cast<const f32x4*>(ab + ((size_t)b * ctot + c + q * 4) * 2);
         const f32x4 e0 = p[0], e1 = p[1];
-        v.x = silu_f(e0.x * v.x + e0.y);
-        v.y = silu_f(e0.z * v.y + e0.w);
-        v.z = silu_f(e1.x * v.z + e1.y);
-        v.w = silu_f(e1.z * v.w + e1.w);
+        v.x = silu_fast(e0.x * v.x + e0.y);
+        v.y = silu_fast(e0.z * v.y + e0.w);
+        v.z = silu_fast(e1.x * v.z + e1.y);
+        v.w = silu_fast(e1.z * v.w + e1.w);
       }
     }
     *reinterpret_cast<f32x4*>(sA + hp * LDP + q * 4) = v;

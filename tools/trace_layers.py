@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Per-layer efficiency from a rocprofv3 kernel trace of bench.py.
+
+Reconstructs the conv_mfma launch sequence of one SVHN and one MNIST32 U-Net
+evaluation (same walk as csrc/rgfm_api.cpp UNetRun::run), attaches algorithmic
+FLOPs to each launch, and prints achieved TFLOP/s per layer for one main-loop
+step (B rows) of the trace.  Usage: trace_layers.py <kernel_trace.csv> [B]"""
+import csv
+import sys
+from collections import defaultdict
+
+
+def unet_convs(in_ch, size, mc, mult, nres=2):
+    """[(name, mode, S_out, cin, cout, skipk)] in launch order (conv_mfma only)."""
+    out = []
+    ch, S = mc, size
+    skips = [ch]
+
+    def res(name, cin, cout, S):
+        out.append((name + ".conv1", 0, S, cin, cout, 0))
+        out.append((name + ".conv2", 0, S, cout, cout, cin if cin != cout else 0))
+
+    e = 0
+    for l, m in enumerate(mult):
+        for _ in range(nres):
+            res(f"enc{e}", ch, mc * m, S)
+            ch = mc * m
+            skips.append(ch)
+            e += 1
+        if l < len(mult) - 1:
+            S //= 2
+            out.append((f"down{l}", 1, S, ch, ch, 0))
+            skips.append(ch)
+    res("mid0", ch, ch, S)
+    res("mid1", ch, ch, S)
+    d = 0
+    for l in range(len(mult) - 1, -1, -1):
+        for _ in range(nres + 1):
+            res(f"dec{d}", ch + skips.pop(), mc * mult[l], S)
+            ch = mc * mult[l]
+            d += 1
+        if l > 0:
+            S *= 2
+            out.append((f"up{l}", 2, S, ch, ch, 0))
+    return out
+
+
+def main():
+    path = sys.argv[1]
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if "conv_mfma_kernel" in r["Kernel_Name"]:
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
+                             int(r["Grid_Size_X"]) // 256, int(r["Grid_Size_Y"])))
+    rows.sort()
+    mn = unet_convs(1, 32, 32, (1, 2))
+    sv = unet_convs(3, 32, 64, (1, 2, 2))
+    per_step = len(mn) + len(sv)
+    # find the first launch of a main-loop step: tiles of the first conv = B*4 (32x32, 4 tiles/sample)
+    start = None
+    for i, r in enumerate(rows):
+        if r[3] == B * 4 and i + per_step <= len(rows) and rows[i + len(mn)][3] == B * 4:
+            # take a step from the middle of the run for steady state
+            start = i
+            if i > len(rows) // 2:
+                break
+    seq = rows[start:start + per_step]
+    tot_fl = tot_t = 0.0
+    agg = defaultdict(lambda: [0.0, 0.0])
+    print(f"{'layer':16s} {'S':>3s} {'cin':>4s} {'cout':>4s} {'grid':>10s} {'us':>8s} {'TF/s':>7s}")
+    for (name, mode, S, cin, cout, sk), (t0, t1, kn, gx, gy) in zip([("m." + a[0],) + a[1:] for a in mn] +
+                                                                      [("s." + a[0],) + a[1:] for a in sv], seq):
+        fl = 2.0 * B * S * S * cout * (9 * cin + sk)
+        us = (t1 - t0) / 1e3
+        tot_fl += fl
+        tot_t += us
+        agg[(S, mode)][0] += fl
+        agg[(S, mode)][1] += us
+        print(f"{name:16s} {S:3d} {cin:4d} {cout:4d} {gx:6d}x{gy:<3d} {us:8.1f} {fl / us / 1e6:7.1f}")
+    print(f"step total: {tot_fl / 1e12:.3f} TFLOP in {tot_t / 1e3:.2f} ms = {tot_fl / tot_t / 1e6:.1f} TF/s")
+    span = (seq[-1][1] - seq[0][0]) / 1e6
+    print(f"wall span of these launches: {span:.2f} ms")
+    for k in sorted(agg):
+        fl, us = agg[k]
+        print(f"  S={k[0]:2d} mode={k[1]}: {us / 1e3:7.2f} ms  {fl / us / 1e6:6.1f} TF/s  ({100 * us / tot_t:.1f}% of conv time)")
+
+
+if __name__ == "__main__":
+    main()
