@@ -305,21 +305,35 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pf_kernel(const ConvArgs a) 
       if (a.temb && sample_ok) v += a.temb[(size_t)(a.temb_per_row ? bw : 0) * a.temb_stride + c];
       add0[nt] = v;
     }
+    if (a.res_mode == 1) {
+      // identity residual: unconditional loads from a clamped pixel -- a per-element branch
+      // around each load makes hipcc wait for every load before issuing the next one
+      // (64 serial L2 round trips per lane).
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int pl = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hp_;
-        const int p = 64 * wave + pl;
-        const bool valid = (g.spt == 1) ? (p < nvalid) : (sample_ok && pl < HW);
-        const size_t pix = pix0 + ((g.spt == 1) ? p : pl);
+        for (int r = 0; r < 16; ++r) {
+          const int pl = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hp_;
+          const int p = 64 * wave + pl;
+          const bool valid = (g.spt == 1) ? (p < nvalid) : (sample_ok && pl < HW);
+          const size_t pix = valid ? pix0 + ((g.spt == 1) ? p : pl) : (sample_ok ? pix0 : 0);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          float v = add0[nt];
-          if (a.res_mode == 1 && valid) v += a.res0[pix * a.Cout + n0 + nt * 32 + l31p];
-          acc[mt][nt][r] = v;
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] = a.res0[pix * a.Cout + n0 + nt * 32 + l31p];
         }
-      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mt][nt][r] += add0[nt];
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mt][nt][r] = add0[nt];
+    }
   }
 
   // ---- per-item decode, once: source pixel offset, validity bit, sample index

@@ -51,7 +51,7 @@ def main():
     rows = []
     with open(path) as f:
         for r in csv.DictReader(f):
-            if "conv_mfma_kernel" in r["Kernel_Name"]:
+            if "conv_mfma" in r["Kernel_Name"]:
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
                              int(r["Grid_Size_X"]) // 256, int(r["Grid_Size_Y"])))
     rows.sort()
