@@ -85,8 +85,8 @@ def sharded_paired_sampler(fm_x, fm_y, ratio_estimator, guidance_method, guidanc
     if guided:
         N = mc_x0.shape[0]
         lo, hi = shard_bounds(N, world, rank)
-        sx = mc_x0[lo:hi].to(device).contiguous()
-        sy = mc_y0[lo:hi].to(device).contiguous()
+        sx = mc_x0[lo:hi].to(device, copy=True).contiguous()  # never clobber the caller's noise
+        sy = mc_y0[lo:hi].to(device, copy=True).contiguous()
         if hi > lo:
             backend.sample_single(fm_x, sx, num_steps)
             backend.sample_single(fm_y, sy, num_steps)
@@ -99,8 +99,8 @@ def sharded_paired_sampler(fm_x, fm_y, ratio_estimator, guidance_method, guidanc
         mc_r = _all_gather_rows(sr, counts, group)
 
     lo, hi = shard_bounds(B, world, rank)
-    x = x0[lo:hi].to(device).contiguous()
-    y = y0[lo:hi].to(device).contiguous()
+    x = x0[lo:hi].to(device, copy=True).contiguous()
+    y = y0[lo:hi].to(device, copy=True).contiguous()
     if hi > lo:
         backend.sample_pair(fm_x, fm_y, x, y, mc_x1, mc_y1, mc_r, num_steps, guidance_strength)
     if world == 1:

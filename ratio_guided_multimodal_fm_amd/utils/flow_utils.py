@@ -47,7 +47,7 @@ def paired_sampler(fm_x, fm_y, ratio_estimator, guidance_method, guidance_streng
     """Shared body of both paired samplers.
 
     `noise` = (x0, y0, mc_x0, mc_y0) overrides the generator draws (parity
-    tests upload CPU-generated noise); tensors are consumed in place.
+    tests upload CPU-generated noise); tensors are copied, never modified.
     """
     fm_x.eval()
     fm_y.eval()
@@ -60,7 +60,7 @@ def paired_sampler(fm_x, fm_y, ratio_estimator, guidance_method, guidance_streng
         x_t = torch.randn(num_samples, *shape_x, device=dev)
         y_t = torch.randn(num_samples, *shape_y, device=dev)
     else:
-        x_t, y_t = noise[0].to(dev).contiguous(), noise[1].to(dev).contiguous()
+        x_t, y_t = noise[0].to(dev, copy=True).contiguous(), noise[1].to(dev, copy=True).contiguous()
 
     mc_x1 = mc_y1 = mc_ratios = None
     if guided:
@@ -69,12 +69,12 @@ def paired_sampler(fm_x, fm_y, ratio_estimator, guidance_method, guidance_streng
         if noise is None:
             mc_x1 = torch.randn(mc_batch_size, *shape_x, device=dev)
         else:
-            mc_x1 = noise[2].to(dev).contiguous()
+            mc_x1 = noise[2].to(dev, copy=True).contiguous()
         _engine.sample_single(fm_x, mc_x1, num_steps)
         if noise is None:
             mc_y1 = torch.randn(mc_batch_size, *shape_y, device=dev)
         else:
-            mc_y1 = noise[3].to(dev).contiguous()
+            mc_y1 = noise[3].to(dev, copy=True).contiguous()
         _engine.sample_single(fm_y, mc_y1, num_steps)
         if verbose:
             print(f"  Generated MC samples: x shape={mc_x1.shape}, y shape={mc_y1.shape}")

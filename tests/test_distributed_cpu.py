@@ -1,0 +1,95 @@
+"""The N>1 path on CPU: world_size-2 (and 3, uneven shards) gloo processes run the
+sharded sampler with the CPU oracle injected as compute backend, and must
+reproduce the single-process result exactly (rows are independent given the
+shared MC set, so sharding may not change a single bit)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+class OracleBackend:
+    """Test-only backend: routes the three compute calls to the CPU oracle."""
+
+    def __init__(self):
+        from oracle import oracle as O
+        from helpers import oracle_net
+        self.O = O
+        self.nets = {"x": oracle_net("mnist32"), "y": oracle_net("svhn"), "r": oracle_net("ratio_ms")}
+
+    def _net(self, model):
+        return self.nets["x"] if model.in_channels == 1 else self.nets["y"]
+
+    def sample_single(self, model, x, num_steps):
+        d, b = self._net(model)
+        x.copy_(torch.from_numpy(self.O.sample_single(d, b, x.numpy(), num_steps)))
+        return x
+
+    def ratios(self, ratio_estimator, mc_x1, mc_y1):
+        kind, b = self.nets["r"]
+        return torch.from_numpy(self.O.ratio_eval(kind, b, mc_x1.numpy(), mc_y1.numpy(), "ratio", "disc"))
+
+    def sample_pair(self, fm_x, fm_y, x, y, mc_x1, mc_y1, mc_r, num_steps, gamma):
+        (dx, bx), (dy, by) = self.nets["x"], self.nets["y"]
+        n = lambda t: None if t is None else t.numpy()
+        ox, oy = self.O.sample_pair(dx, bx, dy, by, x.numpy(), y.numpy(), n(mc_x1), n(mc_y1), n(mc_r), num_steps, gamma)
+        x.copy_(torch.from_numpy(ox))
+        y.copy_(torch.from_numpy(oy))
+        return x, y
+
+
+B, N, S, GAMMA, SEED = 5, 3, 2, 0.5, 123
+
+
+def _run(rank, world, port, guided, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from helpers import make_module, paired_noise
+    from ratio_guided_multimodal_fm_amd.distributed import sharded_paired_sampler
+    fm, fs, rr = make_module("mnist32"), make_module("svhn"), make_module("ratio_ms")
+    noise = paired_noise(SEED, B, N, (1, 32, 32), (3, 32, 32))
+    for gather in ("rank0", "all"):
+        x, y = sharded_paired_sampler(fm, fs, rr if guided else None, "mc_feng" if guided else "none", GAMMA, S,
+                                      noise, torch.device("cpu"), backend=OracleBackend(), gather=gather)
+        if gather == "rank0":
+            assert (x is None) == (rank != 0)
+        if x is not None:
+            np.savez(os.path.join(out_dir, f"out_{gather}_{rank}.npz"), x=x.numpy(), y=y.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,guided", [(2, True), (3, True), (2, False)])
+def test_sharded_equals_single_process(tmp_path, world, guided):
+    from oracle import oracle as O
+    from helpers import oracle_net, paired_noise
+    port = 29600 + world * 7 + int(guided)
+    mp.spawn(_run, args=(world, port, guided, str(tmp_path)), nprocs=world, join=True)
+    (dx, bx), (dy, by), (kind, br) = oracle_net("mnist32"), oracle_net("svhn"), oracle_net("ratio_ms")
+    noise = tuple(v.numpy() for v in paired_noise(SEED, B, N, (1, 32, 32), (3, 32, 32)))
+    rx, ry, _ = O.paired_sampler(dx, bx, dy, by, kind, br, "disc", noise, guided, GAMMA, S)
+    got = np.load(tmp_path / "out_rank0_0.npz")
+    assert np.array_equal(got["x"], rx) and np.array_equal(got["y"], ry)
+    for r in range(world):
+        g = np.load(tmp_path / f"out_all_{r}.npz")
+        assert np.array_equal(g["x"], rx) and np.array_equal(g["y"], ry)
+
+
+def test_shard_bounds_cover_everything():
+    from ratio_guided_multimodal_fm_amd.distributed import shard_bounds
+    for n in (0, 1, 7, 256, 4096, 8193):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
