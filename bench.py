@@ -131,9 +131,9 @@ def main():
         out = one_call(i)
     fence()
     elapsed = time.perf_counter() - t0
-    conv_ms = conv_n = conv_fl = 0.0
+    conv_ms = conv_sum_ms = conv_n = conv_fl = 0.0
     if timers:
-        conv_ms, conv_n, conv_fl = _engine.profile_read(0)
+        conv_ms, conv_sum_ms, conv_n, conv_fl = _engine.profile_read(0)
         _engine.profile(enable=False)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -170,8 +170,12 @@ def main():
             line["roofline"] = {
                 "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                "kernel": "conv_mfma_kernel (fp32 MFMA implicit-GEMM conv, all shapes)",
-                "launches": int(conv_n), "avg_launch_us": 1e3 * conv_ms / max(conv_n, 1),
+                "kernel": "conv_mfma*_kernel (fp32 MFMA implicit-GEMM conv, all shapes)",
+                "launches": int(conv_n), "avg_launch_us": 1e3 * conv_sum_ms / max(conv_n, 1),
+                "busy_ms": conv_ms, "sum_launch_ms": conv_sum_ms,
+                "timing": "hipEvents on the launch streams over the timed region; achieved = algorithmic FLOPs / "
+                          "UNION of the launches' intervals (the two nets of a step run on two streams, so "
+                          "launches overlap; sum_launch_ms double-counts that time; RGFM_OVERLAP=0 serialises)",
                 "kernel_time_share": conv_ms * 1e-3 / elapsed,
             }
         if cpu is not None:

@@ -173,9 +173,12 @@ int rgfm_guidance_apply(const float* x, const float* y, float* vx, float* vy, co
 #define RGFM_KCLASS_COUNT 2
 int rgfm_profile_enable(int enable);
 int rgfm_profile_reset(void);
-/* Waits for the recorded events, then returns accumulated milliseconds, launch
- * count and algorithmic FLOPs (2*MAC) of the class since the last reset. */
-int rgfm_profile_read(int kclass, double* ms, int64_t* launches, double* flops);
+/* Waits for the recorded events, then returns for the class, since the last reset:
+ *   busy_ms  = length of the UNION of the launches' [start, stop] intervals (the two velocity nets
+ *              of a step run on two streams, so launches of one class may overlap in time);
+ *   sum_ms   = plain sum of the launch durations (== busy_ms when nothing overlaps);
+ *   launches, flops = launch count and algorithmic FLOPs (2*MAC). */
+int rgfm_profile_read(int kclass, double* busy_ms, double* sum_ms, int64_t* launches, double* flops);
 
 int rgfm_abi_version(void);
 const char* rgfm_last_error(void);

@@ -5,6 +5,7 @@ blob, workspace, I/O tensors) and naming the stream.  All arithmetic happens
 inside librgfm_hip.so.
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -269,6 +270,32 @@ def sample_single(model, x, num_steps, step_begin=0, step_end=None):
     return x
 
 
+_side_streams = {}
+
+
+def sample_two_streams(fm_x, x, fm_y, y, num_steps):
+    """Two independent unguided integrations (the MC pre-phase) on two HIP streams.
+
+    Same arithmetic as two sample_single calls; the second net runs on a side stream that
+    forks from / joins back into the current stream, so callers keep stream-ordered semantics.
+    """
+    dev = x.device
+    if os.environ.get("RGFM_OVERLAP", "1") == "0":  # A/B switch, same as the library's
+        sample_single(fm_x, x, num_steps)
+        sample_single(fm_y, y, num_steps)
+        return x, y
+    cur = torch.cuda.current_stream(dev)
+    side = _side_streams.get(dev)
+    if side is None:
+        side = _side_streams[dev] = torch.cuda.Stream(dev)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        sample_single(fm_y, y, num_steps)
+    sample_single(fm_x, x, num_steps)
+    cur.wait_stream(side)
+    return x, y
+
+
 def sample_pair(fm_x, fm_y, x, y, mc_x1, mc_y1, mc_ratios, num_steps, gamma, step_begin=0,
                 step_end=None):
     """In-place paired Euler loop with optional MC guidance (rgfm_sample_pair)."""
@@ -326,6 +353,8 @@ def profile(enable=None, reset=False):
 
 
 def profile_read(kclass):
-    ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
-    _lib.check(_lib.lib().rgfm_profile_read(kclass, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)))
-    return ms.value, n.value, fl.value
+    """(busy_ms [union of launch intervals], sum_ms, launches, flops) of a kernel class."""
+    busy, tot, n, fl = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+    _lib.check(_lib.lib().rgfm_profile_read(kclass, ctypes.byref(busy), ctypes.byref(tot), ctypes.byref(n),
+                                            ctypes.byref(fl)))
+    return busy.value, tot.value, n.value, fl.value

@@ -58,7 +58,7 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_size_t, c_void_p]),
     "rgfm_profile_enable": (c_int, [c_int]),
     "rgfm_profile_reset": (c_int, []),
-    "rgfm_profile_read": (c_int, [c_int, P(c_double), P(c_int64), P(c_double)]),
+    "rgfm_profile_read": (c_int, [c_int, P(c_double), P(c_double), P(c_int64), P(c_double)]),
     "rgfm_abi_version": (c_int, []),
     "rgfm_last_error": (ctypes.c_char_p, []),
 }

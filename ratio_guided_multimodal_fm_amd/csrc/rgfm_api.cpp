@@ -7,9 +7,11 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -48,8 +50,11 @@ struct Prof {
   std::vector<int> cls;
   size_t used = 0;
   double flops[RGFM_KCLASS_COUNT] = {0, 0};
-  double ms_done[RGFM_KCLASS_COUNT] = {0, 0};
+  double sum_ms[RGFM_KCLASS_COUNT] = {0, 0};
   int64_t launches[RGFM_KCLASS_COUNT] = {0, 0};
+  std::vector<std::pair<double, double>> iv[RGFM_KCLASS_COUNT];  // [start, stop] ms since the first event
+  hipEvent_t base = nullptr;
+  bool have_base = false;
 } g_prof;
 
 struct ProfScope {
@@ -66,28 +71,52 @@ struct ProfScope {
       }
       g_prof.cls.resize(g_prof.ev.size() / 2);
     }
+    if (!g_prof.have_base) {
+      if (!g_prof.base && hipEventCreate(&g_prof.base) != hipSuccess) return;
+      (void)hipEventRecord(g_prof.base, s);
+      g_prof.have_base = true;
+    }
     idx = g_prof.used;
     g_prof.used += 2;
     g_prof.cls[idx / 2] = kclass;
     g_prof.flops[kclass] += flops;
     g_prof.launches[kclass] += 1;
-    hipEventRecord(g_prof.ev[idx], s);
+    (void)hipEventRecord(g_prof.ev[idx], s);
     active = true;
   }
   ~ProfScope() {
-    if (active) hipEventRecord(g_prof.ev[idx + 1], s);
+    if (active) (void)hipEventRecord(g_prof.ev[idx + 1], s);
   }
 };
 
 int prof_collect() {
   for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
     HIP_TRY(hipEventSynchronize(g_prof.ev[i + 1]));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]));
-    g_prof.ms_done[g_prof.cls[i / 2]] += ms;
+    float t0 = 0.f, t1 = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t0, g_prof.base, g_prof.ev[i]));
+    HIP_TRY(hipEventElapsedTime(&t1, g_prof.base, g_prof.ev[i + 1]));
+    const int k = g_prof.cls[i / 2];
+    g_prof.sum_ms[k] += (double)t1 - (double)t0;
+    g_prof.iv[k].push_back({(double)t0, (double)t1});
   }
   g_prof.used = 0;
   return RGFM_OK;
+}
+
+double prof_union_ms(int k) {
+  auto v = g_prof.iv[k];
+  std::sort(v.begin(), v.end());
+  double total = 0.0, lo = 0.0, hi = -1.0;
+  for (const auto& p : v) {
+    if (p.first > hi) {
+      if (hi >= lo) total += hi - lo;
+      lo = p.first, hi = p.second;
+    } else if (p.second > hi) {
+      hi = p.second;
+    }
+  }
+  if (hi >= lo) total += hi - lo;
+  return total;
 }
 }  // namespace
 
@@ -97,14 +126,19 @@ extern "C" int rgfm_profile_enable(int enable) {
 }
 extern "C" int rgfm_profile_reset(void) {
   int rc = prof_collect();
-  for (int k = 0; k < RGFM_KCLASS_COUNT; ++k) g_prof.flops[k] = g_prof.ms_done[k] = 0, g_prof.launches[k] = 0;
+  for (int k = 0; k < RGFM_KCLASS_COUNT; ++k) {
+    g_prof.flops[k] = g_prof.sum_ms[k] = 0, g_prof.launches[k] = 0;
+    g_prof.iv[k].clear();
+  }
+  g_prof.have_base = false;
   return rc;
 }
-extern "C" int rgfm_profile_read(int kclass, double* ms, int64_t* launches, double* flops) {
+extern "C" int rgfm_profile_read(int kclass, double* busy_ms, double* sum_ms, int64_t* launches, double* flops) {
   if (kclass < 0 || kclass >= RGFM_KCLASS_COUNT) return fail(RGFM_EINVAL, "bad kernel class %d", kclass);
   int rc = prof_collect();
   if (rc) return rc;
-  if (ms) *ms = g_prof.ms_done[kclass];
+  if (busy_ms) *busy_ms = prof_union_ms(kclass);
+  if (sum_ms) *sum_ms = g_prof.sum_ms[kclass];
   if (launches) *launches = g_prof.launches[kclass];
   if (flops) *flops = g_prof.flops[kclass];
   return RGFM_OK;
@@ -172,13 +206,29 @@ bool on_gfx950() {
 }
 
 bool g_conv_init = false;
+int g_num_cus = 256;
+// RGFM_CONV=v3 routes supported convs through the persistent one-block-per-CU kernel of
+// conv_mfma_v3.hip (A/B switch, read per launch; the default is conv_mfma.hip -- see DESIGN.md 4)
+bool use_v3() {
+  const char* e = getenv("RGFM_CONV");
+  return e && strcmp(e, "v3") == 0;
+}
 int ensure_init() {
   if (!on_gfx950()) return fail(RGFM_ENODEVICE, "librgfm_hip needs a gfx950 (MI355X) device; none is current");
   if (!g_conv_init) {
-    if (conv_mfma_init() != 0) return fail(RGFM_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    if (conv_mfma_init() != 0 || conv_v3_init() != 0)
+      return fail(RGFM_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) g_num_cus = p.multiProcessorCount;
     g_conv_init = true;
   }
   return RGFM_OK;
+}
+
+void launch_conv(const ConvArgs& c, int mode, hipStream_t s) {
+  if (use_v3() && conv_v3_supported(c, mode)) launch_conv_v3(c, mode, g_num_cus, s);
+  else launch_conv_mfma(c, mode, s);
 }
 
 }  // namespace
@@ -368,7 +418,7 @@ struct UNetRun {
     c.halo_px = mode == CONV_S2 ? c.g.spt * (2 * c.g.th + 1) * (2 * c.g.W + 1) : c.g.spt * (c.g.th + 2) * (c.g.W + 2);
     const int kprod = 9 * w.cin + (res_mode == 2 ? sk->cin : 0);
     ProfScope p(RGFM_KCLASS_CONV_MFMA, conv_flops(B, So * So, w.cout, kprod), s);
-    launch_conv_mfma(c, mode, s);
+    launch_conv(c, mode, s);
     return o;
   }
   // ResBlock.forward (unet_flexible.py:71-85)
@@ -721,7 +771,7 @@ extern "C" int rgfm_sample_pair_workspace_bytes(const rgfm_unet* hx, const rgfm_
   const size_t ey = unet_eval_bytes(const_cast<rgfm_unet*>(hy), batch);
   const size_t dx = (size_t)hx->d.in_channels * hx->d.img_size * hx->d.img_size;
   const size_t dy = (size_t)hy->d.in_channels * hy->d.img_size * hy->d.img_size;
-  size_t total = table_bytes(hx, 4096) + table_bytes(hy, 4096) + (ex > ey ? ex : ey);
+  size_t total = table_bytes(hx, 4096) + table_bytes(hy, 4096) + ex + ey;  // the two nets run concurrently
   total += ((batch * dx * 4 + 255) & ~(size_t)255) + ((batch * dy * 4 + 255) & ~(size_t)255);
   total += (((size_t)batch * (n_mc > 0 ? n_mc : 1) * 4) + 255) & ~(size_t)255;
   *bytes = total;
@@ -754,20 +804,40 @@ extern "C" int rgfm_sample_pair(rgfm_unet* hx, rgfm_unet* hy, float* x_inout, fl
   float* logp = b.f((size_t)batch * (n_mc > 0 ? n_mc : 1));
   launch_time_table(hx, nullptr, num_steps, step_begin, ns, tx, s);
   launch_time_table(hy, nullptr, num_steps, step_begin, ns, ty, s);
-  const size_t mark = b.off;
+  const size_t mark_x = b.off;
+  const size_t mark_y = mark_x + unet_eval_bytes(hx, batch);
   const double dtd = 1.0 / (double)num_steps;
   const float dt = (float)dtd;
+  // The two velocity nets of a step are independent (reference :119-121): the second one runs on a
+  // side stream forked from / joined back into the caller's stream every step, which fills the CUs
+  // that one net's small-grid launches (8x8 level, kernel tails) leave idle.
+  static hipStream_t side = nullptr;
+  static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  const char* ov = getenv("RGFM_OVERLAP");  // RGFM_OVERLAP=0: both nets on the caller's stream
+  const bool overlap = !(ov && ov[0] == '0');
+  if (overlap && !side) {
+    HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  }
   for (int i = 0; i < ns; ++i) {
     const double t = (double)(step_begin + i) * dtd;
     const bool guided = n_mc > 0 && t > 1e-3;  // `t > eps` test of the reference (:124)
-    b.off = mark;
+    hipStream_t sy = overlap ? side : s;
+    if (overlap) {
+      HIP_TRY(hipEventRecord(ev_fork, s));
+      HIP_TRY(hipStreamWaitEvent(side, ev_fork, 0));
+    }
+    b.off = mark_y;
+    UNetRun ry{hy, batch, &b, sy, ty + (size_t)i * hy->temb_total, 0, false};
+    int rc = ry.run(y_inout, guided ? vy : nullptr, guided ? nullptr : y_inout, dt);
+    if (rc) return rc;
+    if (overlap) HIP_TRY(hipEventRecord(ev_join, side));
+    b.off = mark_x;
     UNetRun rx{hx, batch, &b, s, tx + (size_t)i * hx->temb_total, 0, false};
-    int rc = rx.run(x_inout, guided ? vx : nullptr, guided ? nullptr : x_inout, dt);
+    rc = rx.run(x_inout, guided ? vx : nullptr, guided ? nullptr : x_inout, dt);
     if (rc) return rc;
-    b.off = mark;
-    UNetRun ry{hy, batch, &b, s, ty + (size_t)i * hy->temb_total, 0, false};
-    rc = ry.run(y_inout, guided ? vy : nullptr, guided ? nullptr : y_inout, dt);
-    if (rc) return rc;
+    if (overlap) HIP_TRY(hipStreamWaitEvent(s, ev_join, 0));
     if (guided) {
       rc = guidance_launch(x_inout, y_inout, vx, vy, mc_x1, mc_y1, mc_ratios, batch, n_mc, dx, dy, t, gamma, logp,
                            nullptr, x_inout, y_inout, dt, s);
@@ -918,7 +988,7 @@ struct RatioRun {
           c.out = o.data, c.stats_out = o.stats, c.B = n, c.Cout = o.C, c.g = g;
           c.halo_px = g.spt * (g.th + 2) * (g.W + 2);
           ProfScope p(RGFM_KCLASS_CONV_MFMA, conv_flops(n, S * S, o.C, 9 * cur.C), s);
-          launch_conv_mfma(c, CONV_S1, s);
+          launch_conv(c, CONV_S1, s);
         }
       }
       cur = o;

@@ -156,6 +156,11 @@ void launch_conv_mfma(const ConvArgs& a, int mode, hipStream_t s);
 size_t conv_mfma_lds_bytes(const ConvArgs& a);
 int conv_mfma_init();  // raises the dynamic-LDS limit of every instantiation
 
+// persistent double-buffered variant (conv_mfma_v3.hip); falls back to launch_conv_mfma when unsupported
+bool conv_v3_supported(const ConvArgs& a, int mode);
+int conv_v3_init();
+void launch_conv_v3(const ConvArgs& a, int mode, int num_cus, hipStream_t s);
+
 void launch_conv_in(const ConvInArgs& a, int cin, hipStream_t s);
 void launch_conv_out(const ConvOutArgs& a, int cimg, hipStream_t s);
 void launch_gn_finalize(const GnFinalizeArgs& a, hipStream_t s);

@@ -35,6 +35,10 @@ class HipBackend:
         from . import _engine
         return _engine.sample_single(model, x, num_steps)
 
+    def sample_two(self, fm_x, x, fm_y, y, num_steps):
+        from . import _engine
+        return _engine.sample_two_streams(fm_x, x, fm_y, y, num_steps)
+
     def ratios(self, ratio_estimator, mc_x1, mc_y1):
         return ratio_estimator._engine.eval(mc_x1, mc_y1, "ratio")
 
@@ -88,8 +92,11 @@ def sharded_paired_sampler(fm_x, fm_y, ratio_estimator, guidance_method, guidanc
         sx = mc_x0[lo:hi].to(device, copy=True).contiguous()  # never clobber the caller's noise
         sy = mc_y0[lo:hi].to(device, copy=True).contiguous()
         if hi > lo:
-            backend.sample_single(fm_x, sx, num_steps)
-            backend.sample_single(fm_y, sy, num_steps)
+            if hasattr(backend, "sample_two"):
+                backend.sample_two(fm_x, sx, fm_y, sy, num_steps)
+            else:
+                backend.sample_single(fm_x, sx, num_steps)
+                backend.sample_single(fm_y, sy, num_steps)
             sr = backend.ratios(ratio_estimator, sx, sy)
         else:
             sr = torch.empty(0, device=device)

@@ -66,16 +66,16 @@ def paired_sampler(fm_x, fm_y, ratio_estimator, guidance_method, guidance_streng
     if guided:
         if verbose:
             print(f"  Generating {mc_batch_size} independent MC samples from flows...")
+        # noise in the reference's draw order (x0, y0, mc_x0, mc_y0), then the two independent
+        # pre-phase integrations run concurrently on two HIP streams (the N_mc-row launches are too
+        # small to fill 256 CUs one net at a time)
         if noise is None:
             mc_x1 = torch.randn(mc_batch_size, *shape_x, device=dev)
-        else:
-            mc_x1 = noise[2].to(dev, copy=True).contiguous()
-        _engine.sample_single(fm_x, mc_x1, num_steps)
-        if noise is None:
             mc_y1 = torch.randn(mc_batch_size, *shape_y, device=dev)
         else:
+            mc_x1 = noise[2].to(dev, copy=True).contiguous()
             mc_y1 = noise[3].to(dev, copy=True).contiguous()
-        _engine.sample_single(fm_y, mc_y1, num_steps)
+        _engine.sample_two_streams(fm_x, mc_x1, fm_y, mc_y1, num_steps)
         if verbose:
             print(f"  Generated MC samples: x shape={mc_x1.shape}, y shape={mc_y1.shape}")
         if ratio_estimator.loss_type not in ("disc", "rulsif"):

@@ -58,14 +58,9 @@ def main():
     mn = unet_convs(1, 32, 32, (1, 2))
     sv = unet_convs(3, 32, 64, (1, 2, 2))
     per_step = len(mn) + len(sv)
-    # find the first launch of a main-loop step: tiles of the first conv = B*4 (32x32, 4 tiles/sample)
-    start = None
-    for i, r in enumerate(rows):
-        if r[3] == B * 4 and i + per_step <= len(rows) and rows[i + len(mn)][3] == B * 4:
-            # take a step from the middle of the run for steady state
-            start = i
-            if i > len(rows) // 2:
-                break
+    # the trace ends with the guided main loop: its last per_step conv launches are one Euler step
+    # (MNIST32 net then SVHN net) at batch B
+    start = len(rows) - per_step
     seq = rows[start:start + per_step]
     tot_fl = tot_t = 0.0
     agg = defaultdict(lambda: [0.0, 0.0])
