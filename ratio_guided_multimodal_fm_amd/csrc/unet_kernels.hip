@@ -7,16 +7,18 @@
 namespace rgfm {
 
 // ------------------------------------------------------------------ conv_in
-// input_conv (src/models/unet_flexible.py:155, :219) and the first conv of the
-// ratio encoders (src/models/ratio_flexible.py:195/:245, ratio_estimator.py:46).
-// Workgroup = one 256-pixel tile; wave = one 64-pixel segment; lane = output
-// channel (lane & 31) x pixel parity (lane >> 5).  The image halo is read from
-// LDS as wave-uniform broadcasts; the 9*CIN weights of a channel sit in registers.
+// input_conv (src/models/unet_flexible.py:155, :219) and the first conv of the ratio encoders
+// (src/models/ratio_flexible.py:195/:245, ratio_estimator.py:46): NCHW image -> NHWC features
+// (+ bias, + optional folded-BatchNorm/SiLU epilogue, + GroupNorm partial statistics).
+// Workgroup = one 256-pixel tile, wave = one 64-pixel segment.  lane = output channel; with 64
+// (or more) channels the whole wave works on ONE pixel at a time, with 32 channels the two wave
+// halves take alternate pixels.  The zero-padded halo is staged as one float4 (<= 4 input channels)
+// per pixel, so a tap is a single aligned broadcast ds_read_b128: 9 LDS reads + 9*CIN FMAs per
+// pixel (f32 VALU and LDS issue share the SIMD: the instruction count is the bound).
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_in_kernel(const ConvInArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, h = lane >> 5;
   const TileGeom g = a.g;
   const int W = g.W, H = g.H, HW = g.HW;
   int b0, row0;
@@ -31,23 +33,24 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const ConvInArgs a) {
   int rows_valid = H - row0;
   if (rows_valid > g.th) rows_valid = g.th;
   const int nvalid = rows_valid * W;
-
-  // stage zero-padded image halo: smem[(s*CIN + ci)*per + hy*WR + hx]
-  for (int it = tid; it < g.spt * CIN * per; it += 256) {
-    const int sc = it / per, rem = it - sc * per;
-    const int s = sc / CIN, ci = sc - s * CIN;
+  for (int it = tid; it < g.spt * per; it += 256) {
+    const int s = it / per, rem = it - s * per;
     const int hy = rem / WR, hx = rem - hy * WR;
     const int y = row0 + hy - 1, x = hx - 1, b = b0 + s;
-    float v = 0.f;
-    if (y >= 0 && y < H && x >= 0 && x < W && b < a.B) v = a.x[((size_t)(b * CIN + ci) * H + y) * W + x];
-    smem[it] = v;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (y >= 0 && y < H && x >= 0 && x < W && b < a.B) {
+      const float* p = a.x + ((size_t)b * CIN * H + y) * W + x;
+      v.x = p[0];
+      if (CIN > 1) v.y = p[(size_t)HW];
+      if (CIN > 2) v.z = p[(size_t)2 * HW];
+    }
+    *reinterpret_cast<f32x4*>(smem + 4 * it) = v;
   }
   __syncthreads();
 
   const int bw = (g.spt == 1) ? b0 : b0 + wave;
   const bool sample_ok = bw < a.B;
   const int sidx = (g.spt == 1) ? 0 : wave;
-  // pixel k of this lane: segment pixel pl = 2k + h
   int nw;
   if (g.spt == 1) {
     nw = nvalid - 64 * wave;
@@ -55,63 +58,74 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const ConvInArgs a) {
   } else {
     nw = sample_ok ? HW : 0;
   }
-  const size_t pix0 = (g.spt == 1) ? (size_t)b0 * HW + (size_t)row0 * W + 64 * wave : (size_t)bw * HW;
+  const int q0 = (g.spt == 1) ? 64 * wave : 0;  // first pixel of the segment within the tile
+  const size_t pix0 = (g.spt == 1) ? (size_t)b0 * HW + (size_t)row0 * W + q0 : (size_t)bw * HW;
   const int part = (g.spt == 1) ? (blockIdx.x - b0 * g.tps) * 4 + wave : 0;
 
-  for (int cg = 0; cg < a.C0 / 32; ++cg) {
-    const int c = cg * 32 + l31;
+  const int nh = (a.C0 % 64 == 0) ? 1 : 2;  // pixel-interleave factor of the two wave halves
+  const int cw = 64 / nh;                   // channels per pass
+  const int hh = (nh == 2) ? lane >> 5 : 0;
+  for (int cg = 0; cg < a.C0 / cw; ++cg) {
+    const int c = cg * cw + ((nh == 2) ? (lane & 31) : lane);
     float wr[CIN * 9];
 #pragma unroll
     for (int i = 0; i < CIN * 9; ++i) wr[i] = a.w[(size_t)c * CIN * 9 + i];
     const float bias = a.bias[c];
     const float es = a.ep_scale ? a.ep_scale[c] : 1.f, eh = a.ep_scale ? a.ep_shift[c] : 0.f;
-    float vals[32];
-    float sum = 0.f;
-#pragma unroll
-    for (int k = 0; k < 32; ++k) {
-      const int pl = 2 * k + h;
-      const bool valid = pl < nw;
-      const int q = valid ? ((g.spt == 1) ? 64 * wave + pl : pl) : 0;
-      const int r = q / W, x = q - r * W;
-      const float* base = smem + sidx * CIN * per + r * WR + x;
+    // statistics in one pass around a pivot (the segment's first value): M2 = sum (v-p)^2 - n (mean-p)^2.
+    // Keeping all 64 values for a two-pass form needs a fully unrolled loop, which hipcc turns into
+    // 256 VGPRs + scratch (it hoists every LDS read), i.e. one wave per SIMD.
+    float sum = 0.f, sq = 0.f, pivot = 0.f;
+    int r = (q0 + hh) / W, x = (q0 + hh) - r * W;  // incremental raster walk (no per-pixel division)
+#pragma unroll 2
+    for (int k = hh; k < nw; k += nh) {
+      const float* base = smem + 4 * (sidx * per + r * WR + x);
       float acc = bias;
 #pragma unroll
-      for (int ci = 0; ci < CIN; ++ci)
+      for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) acc += wr[ci * 9 + ky * 3 + kx] * base[ci * per + ky * WR + kx];
-      if (a.ep_scale) acc = silu_f(acc * es + eh);
-      vals[k] = valid ? acc : 0.f;
-      sum += vals[k];
-      if (valid) a.out[(pix0 + pl) * a.C0 + c] = acc;
-    }
-    if (a.stats_out) {
-      sum += __shfl_xor(sum, 32);
-      const float mean = nw > 0 ? sum / (float)nw : 0.f;
-      float m2 = 0.f;
-#pragma unroll
-      for (int k = 0; k < 32; ++k)
-        if (2 * k + h < nw) {
-          const float d = vals[k] - mean;
-          m2 += d * d;
+        for (int kx = 0; kx < 3; ++kx) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(base + 4 * (ky * WR + kx));
+          acc += wr[ky * 3 + kx] * t.x;
+          if (CIN > 1) acc += wr[9 + ky * 3 + kx] * t.y;
+          if (CIN > 2) acc += wr[18 + ky * 3 + kx] * t.z;
         }
-      m2 += __shfl_xor(m2, 32);
-      if (h == 0 && sample_ok) {
-        float2 st;
-        st.x = mean, st.y = m2;
-        *reinterpret_cast<float2*>(a.stats_out + (((size_t)bw * g.nparts + part) * a.C0 + c) * 2) = st;
+      if (a.ep_scale) acc = silu_f(acc * es + eh);
+      a.out[(pix0 + k) * a.C0 + c] = acc;
+      if (k == hh) pivot = acc;
+      const float d = acc - pivot;
+      sum += d;
+      sq += d * d;
+      x += nh;
+      if (x >= W) x -= W, ++r;
+    }
+    if (a.stats_out && sample_ok && nw > 0) {
+      float nme = (float)((nw - hh + nh - 1) / nh);      // pixels this lane saw
+      const float dm = nme > 0.f ? sum / nme : 0.f;      // mean - pivot
+      float mean = pivot + dm;
+      float m2 = sq - nme * dm * dm;
+      m2 = m2 < 0.f ? 0.f : m2;
+      if (nh == 2) {  // Chan-combine the two halves (disjoint pixel sets of the same channel)
+        const float no = __shfl_xor(nme, 32), mo = __shfl_xor(mean, 32), m2o = __shfl_xor(m2, 32);
+        const float nt = nme + no;
+        const float dl = mo - mean;
+        m2 = m2 + m2o + dl * dl * nme * no / nt;
+        mean = mean + dl * no / nt;
+        if (hh) continue;  // lanes 0..31 store
       }
+      float2 st;
+      st.x = mean, st.y = m2;
+      *reinterpret_cast<float2*>(a.stats_out + (((size_t)bw * g.nparts + part) * a.C0 + c) * 2) = st;
     }
   }
 }
 
 void launch_conv_in(const ConvInArgs& a, int cin, hipStream_t s) {
   const int per = (a.g.th + 2) * (a.g.W + 2);
-  const size_t lds = (size_t)a.g.spt * cin * per * sizeof(float);
   dim3 grid(geom_num_tiles(a.g, a.B));
-  if (cin == 1) hipLaunchKernelGGL(conv_in_kernel<1>, grid, dim3(256), lds, s, a);
-  else hipLaunchKernelGGL(conv_in_kernel<3>, grid, dim3(256), lds, s, a);
+  const size_t lds4 = (size_t)a.g.spt * per * 4 * sizeof(float);
+  if (cin == 1) hipLaunchKernelGGL(conv_in_kernel<1>, grid, dim3(256), lds4, s, a);
+  else hipLaunchKernelGGL(conv_in_kernel<3>, grid, dim3(256), lds4, s, a);
 }
 
 // ------------------------------------------------------------------ conv_out
