@@ -167,9 +167,16 @@ def main():
         }
         if timers and conv_ms > 0:
             ach = conv_fl / (conv_ms * 1e-3) / 1e12
+            # HBM bytes per conv launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
+            # separate runs, gfx950 corrections applied by tools/pmc_traffic.py); bench.py cannot collect PMC itself
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
+            if os.path.exists(tpath) and args.batch_per_gpu == 512:
+                with open(tpath) as f:
+                    traffic = json.load(f).get("per_launch_avg_bytes")
             line["roofline"] = {
                 "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                 "kernel": "conv_mfma*_kernel (fp32 MFMA implicit-GEMM conv, all shapes)",
                 "launches": int(conv_n), "avg_launch_us": 1e3 * conv_sum_ms / max(conv_n, 1),
                 "busy_ms": conv_ms, "sum_launch_ms": conv_sum_ms,

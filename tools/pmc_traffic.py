@@ -43,7 +43,7 @@ def main():
     rd = 2.0 * 1024.0 * sum(f_step)
     wr = 1024.0 * sum(w_step)
     alg = 0.0
-    for (name, mode, S, cin, cout, sk) in mn + sv:
+    for (name, mode, S, cin, cout, sk) in sv + mn:
         s_in = S * 2 if mode == 1 else (S // 2 if mode == 2 else S)
         alg += 4.0 * B * (s_in * s_in * cin + S * S * cout)          # input + output
         alg += 4.0 * B * S * S * (sk if sk else (cout if "conv2" in name else 0))  # skip-conv input / identity residual

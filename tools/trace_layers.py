@@ -65,8 +65,9 @@ def main():
     tot_fl = tot_t = 0.0
     agg = defaultdict(lambda: [0.0, 0.0])
     print(f"{'layer':16s} {'S':>3s} {'cin':>4s} {'cout':>4s} {'grid':>10s} {'us':>8s} {'TF/s':>7s}")
-    for (name, mode, S, cin, cout, sk), (t0, t1, kn, gx, gy) in zip([("m." + a[0],) + a[1:] for a in mn] +
-                                                                      [("s." + a[0],) + a[1:] for a in sv], seq):
+    # launch order inside a step: SVHN net first (side stream), then the MNIST net
+    for (name, mode, S, cin, cout, sk), (t0, t1, kn, gx, gy) in zip([("s." + a[0],) + a[1:] for a in sv] +
+                                                                      [("m." + a[0],) + a[1:] for a in mn], seq):
         fl = 2.0 * B * S * S * cout * (9 * cin + sk)
         us = (t1 - t0) / 1e3
         tot_fl += fl
