@@ -4,3 +4,4 @@ from .unet_flexible import (FlexibleUNet, FlowMatchingUNetMNIST, FlowMatchingUNe
                             timestep_embedding)
 from .ratio_estimator import RatioEstimator  # noqa: F401
 from .ratio_flexible import RatioEstimatorMNISTSVHN  # noqa: F401
+from .svhn_classifier import MNISTClassifier32, SVHNClassifier  # noqa: F401

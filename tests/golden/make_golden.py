@@ -19,6 +19,7 @@ only (no reference source).  Reference entry points exercised:
   * CFMSchedule.sample                                      (flow_utils.py:69-100)
   * sample_bimodal_guided                                   (flow_utils.py:178-375)
   * sample_bimodal_guided_mnist_svhn                        (sample_mnist_svhn.py:39-177)
+  * evaluate_coherence, MNISTClassifier32, SVHNClassifier   (evaluate_mnist_svhn.py:28-57, svhn_classifier.py)
 """
 import contextlib
 import io
@@ -47,12 +48,15 @@ from src.models.unet import FlowMatchingUNet as RefUNet28  # noqa: E402
 from src.models.unet_flexible import (FlowMatchingUNetMNIST as RefUNetMNIST,  # noqa: E402
                                       FlowMatchingUNetSVHN as RefUNetSVHN,
                                       timestep_embedding as ref_timestep_embedding)
+from src.evaluate_mnist_svhn import evaluate_coherence as ref_evaluate_coherence  # noqa: E402
+from src.models.svhn_classifier import MNISTClassifier32 as RefMNISTClf, SVHNClassifier as RefSVHNClf  # noqa: E402
 from src.sample_mnist_svhn import sample_bimodal_guided_mnist_svhn as ref_sample_ms  # noqa: E402
 from src.utils.flow_utils import CFMSchedule as RefCFM, sample_bimodal_guided as ref_sample_28  # noqa: E402
 
 torch.set_num_threads(8)
 
-SEED_W = {"unet28": 11, "unet28_y": 12, "mnist32": 13, "svhn": 14, "ratio28": 15, "ratio_ms": 16}
+SEED_W = {"unet28": 11, "unet28_y": 12, "mnist32": 13, "svhn": 14, "ratio28": 15, "ratio_ms": 16,
+          "clf_mnist": 17, "clf_svhn": 18}
 N_PROBE = 256
 
 
@@ -304,8 +308,23 @@ def gen_samplers():
     save("sampler_pair_ms", **out)
 
 
+def gen_coherence():
+    """Classifier logits + coherence accuracy of the reference harness on golden sampler outputs."""
+    from ratio_guided_multimodal_fm_amd.models import svhn_classifier as our_clf
+    cm = build(RefMNISTClf, our_clf.MNISTClassifier32, SEED_W["clf_mnist"])
+    cs = build(RefSVHNClf, our_clf.SVHNClassifier, SEED_W["clf_svhn"])
+    g = np.load(os.path.join(HERE, "sampler_pair_ms.npz"))
+    xs = torch.from_numpy(np.concatenate([g[f"c{i}_x"] for i in range(6)]))
+    ys = torch.from_numpy(np.concatenate([g[f"c{i}_y"] for i in range(6)]))
+    with torch.no_grad():
+        lm, ls = cm(xs), cs(ys)
+    res = ref_evaluate_coherence(xs, ys, cm, cs, 'cpu')
+    save("coherence", logits_mnist=n(lm), logits_svhn=n(ls), coherence_acc=res["coherence_acc"],
+         num_samples=res["num_samples"])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["embedding", "unet_layers", "ratio", "guidance", "samplers"]
+    which = sys.argv[1:] or ["embedding", "unet_layers", "ratio", "guidance", "samplers", "coherence"]
     for w in which:
         {"embedding": gen_embedding, "unet_layers": gen_unet_layers, "ratio": gen_ratio,
-         "guidance": gen_guidance, "samplers": gen_samplers}[w]()
+         "guidance": gen_guidance, "samplers": gen_samplers, "coherence": gen_coherence}[w]()

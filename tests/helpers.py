@@ -12,7 +12,8 @@ from ratio_guided_multimodal_fm_amd.synth import load_synth, paired_noise  # noq
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 # must match tests/golden/make_golden.py
-SEED_W = {"unet28": 11, "unet28_y": 12, "mnist32": 13, "svhn": 14, "ratio28": 15, "ratio_ms": 16}
+SEED_W = {"unet28": 11, "unet28_y": 12, "mnist32": 13, "svhn": 14, "ratio28": 15, "ratio_ms": 16,
+          "clf_mnist": 17, "clf_svhn": 18}
 N_PROBE = 256
 
 _CTORS = {
@@ -22,6 +23,8 @@ _CTORS = {
     "svhn": lambda: M.FlowMatchingUNetSVHN(),
     "ratio28": lambda: M.RatioEstimator(),
     "ratio_ms": lambda: M.RatioEstimatorMNISTSVHN(),
+    "clf_mnist": lambda: __import__("ratio_guided_multimodal_fm_amd.models.svhn_classifier", fromlist=["x"]).MNISTClassifier32(),
+    "clf_svhn": lambda: __import__("ratio_guided_multimodal_fm_amd.models.svhn_classifier", fromlist=["x"]).SVHNClassifier(),
 }
 
 
