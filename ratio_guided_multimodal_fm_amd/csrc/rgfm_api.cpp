@@ -184,6 +184,8 @@ struct Cursor {
 struct ConvW {  // one packed conv
   size_t w_raw = 0, b = 0;  // offsets into the params blob
   size_t w_pk = 0;          // offset into the packed buffer
+  size_t w_wino = 0;        // offset into the Winograd-transformed buffer (3x3, Cout % 64 == 0 only)
+  bool has_wino = false;
   int cin = 0, cout = 0, taps = 9;
 };
 
@@ -216,7 +218,7 @@ bool use_v3() {
 int ensure_init() {
   if (!on_gfx950()) return fail(RGFM_ENODEVICE, "librgfm_hip needs a gfx950 (MI355X) device; none is current");
   if (!g_conv_init) {
-    if (conv_mfma_init() != 0 || conv_v3_init() != 0)
+    if (conv_mfma_init() != 0 || conv_v3_init() != 0 || conv_wino_init() != 0)
       return fail(RGFM_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     int dev = 0;
     hipDeviceProp_t p;
@@ -226,8 +228,15 @@ int ensure_init() {
   return RGFM_OK;
 }
 
-void launch_conv(const ConvArgs& c, int mode, hipStream_t s) {
-  if (use_v3() && conv_v3_supported(c, mode)) launch_conv_v3(c, mode, g_num_cus, s);
+// RGFM_WINO=1 routes eligible stride-1 3x3 convs through the Winograd F(2x2,3x3) kernel (read per launch)
+bool use_wino() {
+  const char* e = getenv("RGFM_WINO");
+  return e && e[0] == '1';
+}
+
+void launch_conv(const ConvArgs& c, int mode, const float* wino, hipStream_t s) {
+  if (wino && use_wino() && conv_wino_supported(c, mode)) launch_conv_wino(c, mode, wino, s);
+  else if (use_v3() && conv_v3_supported(c, mode)) launch_conv_v3(c, mode, g_num_cus, s);
   else launch_conv_mfma(c, mode, s);
 }
 
@@ -238,6 +247,8 @@ struct rgfm_unet {
   rgfm_unet_desc d;
   float* params = nullptr;  // device copy of the state_dict-order blob
   float* packed = nullptr;  // packed conv weights
+  float* wino = nullptr;    // Winograd-transformed 3x3 weights
+  size_t n_wino = 0;
   float* freqs = nullptr;
   TimeLinear* lin_dev = nullptr;
   size_t n_params = 0, n_packed = 0;
@@ -262,7 +273,7 @@ namespace {
 // is identical) and records blob offsets.  Returns the total float count.
 size_t plan_unet(const rgfm_unet_desc& d, rgfm_unet* h) {
   Cursor c;
-  Cursor pk;
+  Cursor pk, wk;
   const int mc = d.model_channels, temb = 4 * mc;
   std::vector<ResW> enc, mid, dec;
   std::vector<ConvW> down, up;
@@ -273,6 +284,8 @@ size_t plan_unet(const rgfm_unet_desc& d, rgfm_unet* h) {
     w.w_raw = c.take((size_t)cout * cin * taps);
     w.b = c.take(cout);
     w.w_pk = pk.take((size_t)cout * cin * taps);
+    w.has_wino = taps == 9 && cout % 64 == 0 && cin % 16 == 0;
+    if (w.has_wino) w.w_wino = wk.take((size_t)cout * cin * 16);
     return w;
   };
   auto res = [&](int cin, int cout) {
@@ -329,6 +342,7 @@ size_t plan_unet(const rgfm_unet_desc& d, rgfm_unet* h) {
     h->final_ch = ch;
     h->temb_total = temb_off;
     h->n_packed = pk.off;
+    h->n_wino = wk.off;
   }
   return c.off;
 }
@@ -354,6 +368,7 @@ int check_desc(const rgfm_unet_desc* d) {
 
 void pack_one(const rgfm_unet* h, const ConvW& w, hipStream_t s) {
   launch_pack_conv(h->params + w.w_raw, h->packed + w.w_pk, w.cout, w.cin, w.taps, nt32_of(w.cout), s);
+  if (w.has_wino) launch_wino_pack(h->params + w.w_raw, h->wino + w.w_wino, w.cout, w.cin, s);
 }
 
 double conv_flops(int B, int HW, int cout, int kprod) { return 2.0 * B * HW * (double)cout * kprod; }
@@ -418,7 +433,7 @@ struct UNetRun {
     c.halo_px = mode == CONV_S2 ? c.g.spt * (2 * c.g.th + 1) * (2 * c.g.W + 1) : c.g.spt * (c.g.th + 2) * (c.g.W + 2);
     const int kprod = 9 * w.cin + (res_mode == 2 ? sk->cin : 0);
     ProfScope p(RGFM_KCLASS_CONV_MFMA, conv_flops(B, So * So, w.cout, kprod), s);
-    launch_conv(c, mode, s);
+    launch_conv(c, mode, w.has_wino ? h->wino + w.w_wino : nullptr, s);
     return o;
   }
   // ResBlock.forward (unet_flexible.py:71-85)
@@ -546,6 +561,7 @@ extern "C" int rgfm_unet_create(const rgfm_unet_desc* desc, const float* params_
   };
   if (hipMalloc(&h->params, n_floats * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(params)");
   if (hipMalloc(&h->packed, (h->n_packed + 4) * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(packed)");
+  if (hipMalloc(&h->wino, (h->n_wino + 4) * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(wino)");
   if (hipMemcpyAsync(h->params, params_dev, n_floats * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
     return bail(RGFM_EHIP, "hipMemcpyAsync(params)");
   for (const auto* v : {&h->enc, &h->mid, &h->dec})
@@ -578,6 +594,7 @@ extern "C" void rgfm_unet_destroy(rgfm_unet* h) {
   if (!h) return;
   if (h->params) (void)hipFree(h->params);
   if (h->packed) (void)hipFree(h->packed);
+  if (h->wino) (void)hipFree(h->wino);
   if (h->freqs) (void)hipFree(h->freqs);
   if (h->lin_dev) (void)hipFree(h->lin_dev);
   delete h;
@@ -988,7 +1005,7 @@ struct RatioRun {
           c.out = o.data, c.stats_out = o.stats, c.B = n, c.Cout = o.C, c.g = g;
           c.halo_px = g.spt * (g.th + 2) * (g.W + 2);
           ProfScope p(RGFM_KCLASS_CONV_MFMA, conv_flops(n, S * S, o.C, 9 * cur.C), s);
-          launch_conv(c, CONV_S1, s);
+          launch_conv(c, CONV_S1, nullptr, s);
         }
       }
       cur = o;

@@ -161,6 +161,12 @@ bool conv_v3_supported(const ConvArgs& a, int mode);
 int conv_v3_init();
 void launch_conv_v3(const ConvArgs& a, int mode, int num_cus, hipStream_t s);
 
+// Winograd F(2x2,3x3) variant (conv_wino.hip) for stride-1 3x3 convs at 8/16/32 resolution, Cout % 64 == 0
+bool conv_wino_supported(const ConvArgs& a, int mode);
+int conv_wino_init();
+void launch_conv_wino(const ConvArgs& a, int mode, const float* upk, hipStream_t s);
+void launch_wino_pack(const float* w, float* out, int Cout, int Cin, hipStream_t s);
+
 void launch_conv_in(const ConvInArgs& a, int cin, hipStream_t s);
 void launch_conv_out(const ConvOutArgs& a, int cimg, hipStream_t s);
 void launch_gn_finalize(const GnFinalizeArgs& a, hipStream_t s);

@@ -279,3 +279,19 @@ def test_full_size_properties(dev):
                            my1.cpu().numpy(), r.cpu().numpy(), S, 0.5, 0, nsteps)
     assert maxdiff(xa[rows].cpu().numpy(), ox) < TOL_SAMPLER
     assert maxdiff(ya[rows].cpu().numpy(), oy) < TOL_SAMPLER
+
+
+@pytest.mark.parametrize("env", [{"RGFM_WINO": "1"}, {"RGFM_CONV": "v3"}])
+@pytest.mark.parametrize("tag,B", [("svhn", 5), ("mnist32", 3)])
+def test_experimental_conv_variants_keep_parity(dev, env, tag, B, monkeypatch):
+    """The opt-in conv variants (Winograd F(2x2,3x3): RGFM_WINO=1; persistent one-block-per-CU kernel:
+    RGFM_CONV=v3; both read per launch) must stay inside the same tolerance as the default path."""
+    m = make_module(tag, dev)
+    desc, blob = oracle_net(tag)
+    x = torch.randn(B, *SHAPES[tag], generator=torch.Generator().manual_seed(5))
+    t = torch.rand(B, generator=torch.Generator().manual_seed(6))
+    ro = O.unet_forward(desc, blob, x.numpy(), t.numpy())
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    out = m(x.to(dev), t.to(dev)).cpu().numpy()
+    assert maxdiff(out, ro) < TOL_EVAL
