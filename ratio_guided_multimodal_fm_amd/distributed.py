@@ -50,7 +50,7 @@ class HipBackend:
 def _all_gather_rows(t, counts, group):
     """all_gather of row-sharded tensors with possibly unequal row counts."""
     world = len(counts)
-    if world == 1:
+    if not dist.is_initialized():
         return t
     mx = max(counts)
     if t.shape[0] < mx:
@@ -110,7 +110,7 @@ def sharded_paired_sampler(fm_x, fm_y, ratio_estimator, guidance_method, guidanc
     y = y0[lo:hi].to(device, copy=True).contiguous()
     if hi > lo:
         backend.sample_pair(fm_x, fm_y, x, y, mc_x1, mc_y1, mc_r, num_steps, guidance_strength)
-    if world == 1:
+    if not dist.is_initialized():
         return x, y
     counts = [shard_bounds(B, world, r)[1] - shard_bounds(B, world, r)[0] for r in range(world)]
     if gather == "all":

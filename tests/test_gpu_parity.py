@@ -295,3 +295,26 @@ def test_experimental_conv_variants_keep_parity(dev, env, tag, B, monkeypatch):
         monkeypatch.setenv(k, v)
     out = m(x.to(dev), t.to(dev)).cpu().numpy()
     assert maxdiff(out, ro) < TOL_EVAL
+
+
+def test_rccl_collectives_single_rank(dev):
+    """The collective calls of the sharded sampler (all_gather_into_tensor, gather) on HIP tensors over
+    the RCCL backend.  One rank only -- a 1-GPU box cannot host two RCCL ranks; the multi-rank logic is
+    covered by the gloo tests in tests/test_distributed_cpu.py."""
+    import os
+    import torch.distributed as dist
+    from ratio_guided_multimodal_fm_amd.distributed import sharded_paired_sampler
+    from ratio_guided_multimodal_fm_amd.utils.flow_utils import paired_sampler
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29571")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        fm, fs, rr = make_module("mnist32", dev), make_module("svhn", dev), make_module("ratio_ms", dev)
+        noise = paired_noise(11, 5, 6, (1, 32, 32), (3, 32, 32))
+        xs, ys = sharded_paired_sampler(fm, fs, rr, "mc_feng", 0.5, 4, noise, dev, gather="rank0")
+        xa, ya = sharded_paired_sampler(fm, fs, rr, "mc_feng", 0.5, 4, noise, dev, gather="all")
+        xr, yr = paired_sampler(fm, fs, rr, "mc_feng", 0.5, 5, 4, dev, 6, (1, 32, 32), (3, 32, 32), noise=noise,
+                                verbose=False)
+        assert torch.equal(xs, xr) and torch.equal(ys, yr) and torch.equal(xa, xr) and torch.equal(ya, yr)
+    finally:
+        dist.destroy_process_group()
