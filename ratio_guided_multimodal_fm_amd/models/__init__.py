@@ -1,4 +1,5 @@
 """Model API of the sampler path (mirrors the reference ``src/models``)."""
+from .flow_matching import FlowMatchingModel  # noqa: F401
 from .unet import FlowMatchingUNet, UNetMNIST  # noqa: F401
 from .unet_flexible import (FlexibleUNet, FlowMatchingUNetMNIST, FlowMatchingUNetSVHN,  # noqa: F401
                             timestep_embedding)
