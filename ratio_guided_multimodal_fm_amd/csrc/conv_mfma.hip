@@ -243,6 +243,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 //     and written to LDS after them, so their latency hides under the matrix work
 //     instead of stalling both co-resident blocks (which run in lockstep).
 // ------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) f32x4 pf_gf32x4;  // explicit global loads (never flat)
 constexpr int MAXIT = 7;  // ceil(max halo_px * 4 / 256): halo_px <= 448 in these modes
 
 template <int NT, int MODE>
@@ -394,21 +395,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pf_kernel(const ConvArgs a) 
       if (c < a.R0) src = a.res0, cs = a.R0, cc = c;
       else src = a.res1, cs = a.R1, cc = c - a.R0;
     }
+    // Unconditional, clamped loads (padding / out-of-range items read pixel 0 and are zeroed at commit).
+    // A load under a per-item branch merges with the zero-initialised register at the join, which makes
+    // hipcc wait vmcnt(0) right there -- i.e. BEFORE the MFMAs the prefetch is supposed to hide under.
 #pragma unroll
-    for (int j = 0; j < MAXIT; ++j) {
-      ra[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if ((okmask >> j) & 1u) ra[j] = *reinterpret_cast<const f32x4*>(src + (size_t)poff[j] * cs + cc + q4 * 4);
-    }
+    for (int j = 0; j < MAXIT; ++j) ra[j] = *(const pf_gf32x4*)(src + (size_t)poff[j] * cs + cc + q4 * 4);
     const float* wsrc = skip ? a.wskip + ((size_t)(blockIdx.y * nch_skip + (ch - nch_main))) * (32 * NT * KC)
                              : a.wpk + ((size_t)(blockIdx.y * nch_main + ch) * 9) * (32 * NT * KC);
     const int nbit = skip ? 32 * NT * 4 : 9 * 32 * NT * 4;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int it = tid + 256 * j;
-      if (it < nbit) rb[j] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)it * 4);
+      rb[j] = *(const pf_gf32x4*)(wsrc + (size_t)(it < nbit ? it : 0) * 4);
     }
-    if (!skip && a.ab && tid < g.spt * 8 && b0 + (tid >> 3) < a.B)
-      rab = *reinterpret_cast<const f32x4*>(a.ab + ((size_t)(b0 + (tid >> 3)) * cin + c + 2 * (tid & 7)) * 2);
+    if (!skip && a.ab) {  // wave-uniform; lanes beyond the table read entry 0 (never used)
+      const bool use = tid < g.spt * 8 && b0 + (tid >> 3) < a.B;
+      const size_t o = use ? ((size_t)(b0 + (tid >> 3)) * cin + c + 2 * (tid & 7)) * 2 : 0;
+      rab = *(const pf_gf32x4*)(a.ab + o);
+    }
   };
 
   auto commit = [&](int ch) {
@@ -421,7 +425,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pf_kernel(const ConvArgs a) 
       const int it = tid + 256 * j;
       if (it < nA) {
         f32x4 v = ra[j];
-        if (xform && ((okmask >> j) & 1u)) {
+        const bool okj = (okmask >> j) & 1u;
+        if (!okj) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (xform && okj) {
           const int s = (smask >> (2 * j)) & 3u;
           const f32x4 e0 = *reinterpret_cast<const f32x4*>(sAB + (s * 16 + q4 * 4) * 2);
           const f32x4 e1 = *reinterpret_cast<const f32x4*>(sAB + (s * 16 + q4 * 4) * 2 + 4);
