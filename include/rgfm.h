@@ -147,7 +147,11 @@ int rgfm_sample_single(rgfm_unet* h, float* x_inout, int batch, int num_steps, i
  *   mc_x1[N,..], mc_y1[N,..], mc_ratios[N]: terminal MC set; pass n_mc = 0 (and
  *   null pointers) for guidance_method == 'none'.
  *   gamma = guidance_strength (not clamped).  Guidance is applied on steps with
- *   t = step/num_steps > 1e-3, as in the reference. */
+ *   t = step/num_steps > 1e-3, as in the reference.
+ *   The two networks of a step are independent; the second one is enqueued on a
+ *   library-owned side stream that is forked from and joined back into `stream`
+ *   with events every step (RGFM_OVERLAP=0 keeps everything on `stream`), so the
+ *   call is still ordered with respect to `stream` on entry and on return. */
 int rgfm_sample_pair_workspace_bytes(const rgfm_unet* hx, const rgfm_unet* hy, int batch, int n_mc,
                                      size_t* bytes);
 int rgfm_sample_pair(rgfm_unet* hx, rgfm_unet* hy, float* x_inout, float* y_inout,

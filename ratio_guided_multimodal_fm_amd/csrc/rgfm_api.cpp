@@ -828,15 +828,23 @@ extern "C" int rgfm_sample_pair(rgfm_unet* hx, rgfm_unet* hy, float* x_inout, fl
   // The two velocity nets of a step are independent (reference :119-121): the second one runs on a
   // side stream forked from / joined back into the caller's stream every step, which fills the CUs
   // that one net's small-grid launches (8x8 level, kernel tails) leave idle.
-  static hipStream_t side = nullptr;
-  static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  struct Side {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+  };
+  static Side sides[16];  // one per device ordinal (one process may drive several devices)
   const char* ov = getenv("RGFM_OVERLAP");  // RGFM_OVERLAP=0: both nets on the caller's stream
-  const bool overlap = !(ov && ov[0] == '0');
-  if (overlap && !side) {
-    HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  const bool overlap = !(ov && ov[0] == '0') && dev >= 0 && dev < 16;
+  Side& sd = sides[overlap ? dev : 0];
+  if (overlap && !sd.stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming));
   }
+  hipStream_t side = sd.stream;
+  hipEvent_t ev_fork = sd.fork, ev_join = sd.join;
   for (int i = 0; i < ns; ++i) {
     const double t = (double)(step_begin + i) * dtd;
     const bool guided = n_mc > 0 && t > 1e-3;  // `t > eps` test of the reference (:124)
