@@ -39,6 +39,9 @@ def lib():
             build()
         L = ctypes.CDLL(_SO)
         L.ro_unet_param_floats.restype = ctypes.c_size_t
+        L.ro_fm_param_floats.restype = ctypes.c_size_t
+        L.ro_fm_forward.restype = None
+        L.ro_fm_time_embedding.restype = None
         L.ro_ratio_param_floats.restype = ctypes.c_size_t
         L.ro_unet_num_activations.restype = ctypes.c_int
         L.ro_num_threads.restype = ctypes.c_int
@@ -195,3 +198,22 @@ def paired_sampler(desc_x, params_x, desc_y, params_y, ratio_kind, ratio_params,
         r = ratio_eval(ratio_kind, ratio_params, mx1, my1, "ratio", loss)
     x, y = sample_pair(desc_x, params_x, desc_y, params_y, x0, y0, mx1, my1, r, num_steps, gamma)
     return x, y, (mx1, my1, r)
+
+
+def fm_forward(params, x, t):
+    """FlowMatchingModel ('original' net) forward: x [B,1,28,28], t [1] or [B]."""
+    L = lib()
+    params, pp = _f(params)
+    assert params.size == L.ro_fm_param_floats(), "parameter blob size"
+    x, xp = _f(x)
+    t, tp = _f(np.atleast_1d(t))
+    out = np.empty_like(x)
+    L.ro_fm_forward(pp, xp, tp, ctypes.c_int(t.size), out.ctypes.data_as(F32P), ctypes.c_int(x.shape[0]))
+    return out
+
+
+def fm_time_embedding(t, dim=128):
+    t, tp = _f(t)
+    out = np.empty((t.shape[0], dim), np.float32)
+    lib().ro_fm_time_embedding(tp, ctypes.c_int(t.shape[0]), ctypes.c_int(dim), out.ctypes.data_as(F32P))
+    return out

@@ -759,3 +759,128 @@ void ro_sample_pair(const ro_unet_desc* ddx, const float* px, const ro_unet_desc
   free(vx);
   free(vy);
 }
+
+/* ---------------------------------------------------------------- FlowMatchingModel ("original" net) */
+
+/* nn.ConvTranspose2d(k=4, stride=2, padding=1): in [Ci,H,W] -> out [Co,2H,2W]; w [Ci][Co][4][4] */
+static void deconv4x4s2(const float* in, int Ci, int H, int W, const float* w, const float* b, int Co,
+                        float* out) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  for (int co = 0; co < Co; ++co)
+    for (int i = 0; i < Ho * Wo; ++i) out[(size_t)co * Ho * Wo + i] = b[co];
+  for (int ci = 0; ci < Ci; ++ci)
+    for (int co = 0; co < Co; ++co) {
+      const float* wk = w + ((size_t)ci * Co + co) * 16;
+      float* o = out + (size_t)co * Ho * Wo;
+      for (int iy = 0; iy < H; ++iy)
+        for (int ix = 0; ix < W; ++ix) {
+          const float v = in[((size_t)ci * H + iy) * W + ix];
+          for (int ky = 0; ky < 4; ++ky) {
+            const int oy = 2 * iy - 1 + ky;
+            if (oy < 0 || oy >= Ho) continue;
+            for (int kx = 0; kx < 4; ++kx) {
+              const int ox = 2 * ix - 1 + kx;
+              if (ox < 0 || ox >= Wo) continue;
+              o[(size_t)oy * Wo + ox] += v * wk[ky * 4 + kx];
+            }
+          }
+        }
+    }
+}
+
+size_t ro_fm_param_floats(void) {
+  /* encoder: conv1..4 + gn1..4 + fc ; decoder: fc1, deconv1, gn1, deconv2, gn2, conv3, gn3, conv_out */
+  size_t n = 0;
+  const int ec[5] = {1, 32, 64, 128, 256};
+  for (int i = 0; i < 4; ++i) n += (size_t)ec[i + 1] * ec[i] * 9 + 3 * ec[i + 1];
+  n += (size_t)256 * 12544 + 256;
+  n += (size_t)12544 * 384 + 12544;
+  n += (size_t)256 * 128 * 16 + 128 + 2 * 128;
+  n += (size_t)128 * 64 * 16 + 64 + 2 * 64;
+  n += (size_t)32 * 64 * 9 + 32 + 2 * 32;
+  n += (size_t)32 * 9 + 1;
+  return n;
+}
+
+/* SinusoidalPositionEmbeddings (src/models/flow_matching.py:17-31): sin half first, denominator half-1 */
+void ro_fm_time_embedding(const float* t, int n, int dim, float* out) {
+  const int half = dim / 2;
+  const float neg = (float)(-(log(10000.0) / (double)(half - 1)));
+  for (int b = 0; b < n; ++b)
+    for (int i = 0; i < half; ++i) {
+      const float a = t[b] * expf((float)i * neg);
+      out[(size_t)b * dim + i] = sinf(a);
+      out[(size_t)b * dim + half + i] = cosf(a);
+    }
+}
+
+/* FlowMatchingModel.forward (src/models/flow_matching.py:153-173; encoder :56-72, decoder :100-124) */
+void ro_fm_forward(const float* params, const float* x, const float* t, int t_count, float* out, int B) {
+#pragma omp parallel for schedule(dynamic)
+  for (int b = 0; b < B; ++b) {
+    cursor c = {params};
+    const int ec[5] = {1, 32, 64, 128, 256}, es[4] = {1, 2, 2, 1};
+    int S = 28;
+    float* h = fmalloc(784);
+    memcpy(h, x + (size_t)b * 784, 784 * sizeof(float));
+    for (int i = 0; i < 4; ++i) {
+      const float* cw = take(&c, (size_t)ec[i + 1] * ec[i] * 9);
+      const float* cb = take(&c, ec[i + 1]);
+      const float* gw = take(&c, ec[i + 1]);
+      const float* gb = take(&c, ec[i + 1]);
+      const int So = (S + 2 - 3) / es[i] + 1;
+      float* o = fmalloc((size_t)ec[i + 1] * So * So);
+      conv3x3(h, ec[i], S, S, cw, cb, ec[i + 1], es[i], o);
+      free(h);
+      h = fmalloc((size_t)ec[i + 1] * So * So);
+      groupnorm(o, ec[i + 1], So * So, 8, gw, gb, 1, h);
+      free(o);
+      S = So;
+    }
+    const float* fw = take(&c, (size_t)256 * 12544);
+    const float* fb = take(&c, 256);
+    float comb[384];
+    linear(fw, fb, h, 12544, 256, comb);
+    free(h);
+    const float tb = t[t_count == 1 ? 0 : b];
+    ro_fm_time_embedding(&tb, 1, 128, comb + 256);
+    const float* f1w = take(&c, (size_t)12544 * 384);
+    const float* f1b = take(&c, 12544);
+    float* d0 = fmalloc(12544);
+    linear(f1w, f1b, comb, 384, 12544, d0);
+    const float* d1w = take(&c, (size_t)256 * 128 * 16);
+    const float* d1b = take(&c, 128);
+    const float* g1w = take(&c, 128);
+    const float* g1b = take(&c, 128);
+    float* u1 = fmalloc((size_t)128 * 14 * 14);
+    deconv4x4s2(d0, 256, 7, 7, d1w, d1b, 128, u1);
+    free(d0);
+    float* a1 = fmalloc((size_t)128 * 196);
+    groupnorm(u1, 128, 196, 8, g1w, g1b, 1, a1);
+    free(u1);
+    const float* d2w = take(&c, (size_t)128 * 64 * 16);
+    const float* d2b = take(&c, 64);
+    const float* g2w = take(&c, 64);
+    const float* g2b = take(&c, 64);
+    float* u2 = fmalloc((size_t)64 * 784);
+    deconv4x4s2(a1, 128, 14, 14, d2w, d2b, 64, u2);
+    free(a1);
+    float* a2 = fmalloc((size_t)64 * 784);
+    groupnorm(u2, 64, 784, 8, g2w, g2b, 1, a2);
+    free(u2);
+    const float* c3w = take(&c, (size_t)32 * 64 * 9);
+    const float* c3b = take(&c, 32);
+    const float* g3w = take(&c, 32);
+    const float* g3b = take(&c, 32);
+    float* u3 = fmalloc((size_t)32 * 784);
+    conv3x3(a2, 64, 28, 28, c3w, c3b, 32, 1, u3);
+    free(a2);
+    float* a3 = fmalloc((size_t)32 * 784);
+    groupnorm(u3, 32, 784, 8, g3w, g3b, 1, a3);
+    free(u3);
+    const float* cow = take(&c, 32 * 9);
+    const float* cob = take(&c, 1);
+    conv3x3(a3, 32, 28, 28, cow, cob, 1, 1, out + (size_t)b * 784);
+    free(a3);
+  }
+}

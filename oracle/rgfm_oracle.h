@@ -58,6 +58,10 @@ void ro_sample_pair(const ro_unet_desc* dx, const float* px, const ro_unet_desc*
                     float* x, float* y, const float* mc_x1, const float* mc_y1,
                     const float* mc_ratios, int n_mc, int B, int num_steps, double gamma,
                     int step_begin, int step_end);
+/* FlowMatchingModel ("--model original", src/models/flow_matching.py), 1x28x28, feature 256, time 128 */
+size_t ro_fm_param_floats(void);
+void ro_fm_time_embedding(const float* t, int n, int dim, float* out);
+void ro_fm_forward(const float* params, const float* x, const float* t, int t_count, float* out, int B);
 int ro_num_threads(void);
 
 #ifdef __cplusplus

@@ -42,6 +42,7 @@ import torch.nn as nn  # noqa: E402
 from ratio_guided_multimodal_fm_amd import models as ours  # noqa: E402
 from ratio_guided_multimodal_fm_amd.synth import paired_noise, synth_state_dict  # noqa: E402
 
+from src.models.flow_matching import FlowMatchingModel as RefFMOriginal  # noqa: E402
 from src.models.ratio_estimator import RatioEstimator as RefRatio28  # noqa: E402
 from src.models.ratio_flexible import RatioEstimatorMNISTSVHN as RefRatioMS  # noqa: E402
 from src.models.unet import FlowMatchingUNet as RefUNet28  # noqa: E402
@@ -56,7 +57,7 @@ from src.utils.flow_utils import CFMSchedule as RefCFM, sample_bimodal_guided as
 torch.set_num_threads(8)
 
 SEED_W = {"unet28": 11, "unet28_y": 12, "mnist32": 13, "svhn": 14, "ratio28": 15, "ratio_ms": 16,
-          "clf_mnist": 17, "clf_svhn": 18}
+          "clf_mnist": 17, "clf_svhn": 18, "fm_original": 19}
 N_PROBE = 256
 
 
@@ -323,8 +324,25 @@ def gen_coherence():
          num_samples=res["num_samples"])
 
 
+def gen_fm_original():
+    """FlowMatchingModel (--model original): forward at shared and per-row t, its time embedding, and
+    CFMSchedule.sample driven with it (flow_utils.py:69-100)."""
+    ref = build(RefFMOriginal, ours.FlowMatchingModel, SEED_W["fm_original"])
+    g = torch.Generator().manual_seed(79)
+    x = torch.randn(3, 1, 28, 28, generator=g)
+    out = {"x_fingerprint": n(x.reshape(-1)[:8])}
+    with torch.no_grad():
+        out["v_t037"] = n(ref(x, torch.full((3,), 0.37)))
+        out["v_tvec"] = n(ref(x, torch.tensor([0.0, 0.5, 0.99])))
+        out["temb"] = n(ref.time_embed(torch.tensor([0.0, 0.01, 0.5, 0.99])))
+    torch.manual_seed(22)
+    out["sample"] = n(quiet(RefCFM().sample, ref, 3, 10, 'cpu'))
+    save("fm_original", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["embedding", "unet_layers", "ratio", "guidance", "samplers", "coherence"]
+    which = sys.argv[1:] or ["embedding", "unet_layers", "ratio", "guidance", "samplers", "coherence", "fm_original"]
     for w in which:
         {"embedding": gen_embedding, "unet_layers": gen_unet_layers, "ratio": gen_ratio,
-         "guidance": gen_guidance, "samplers": gen_samplers, "coherence": gen_coherence}[w]()
+         "guidance": gen_guidance, "samplers": gen_samplers, "coherence": gen_coherence,
+         "fm_original": gen_fm_original}[w]()

@@ -13,7 +13,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 # must match tests/golden/make_golden.py
 SEED_W = {"unet28": 11, "unet28_y": 12, "mnist32": 13, "svhn": 14, "ratio28": 15, "ratio_ms": 16,
-          "clf_mnist": 17, "clf_svhn": 18}
+          "clf_mnist": 17, "clf_svhn": 18, "fm_original": 19}
 N_PROBE = 256
 
 _CTORS = {
@@ -23,6 +23,7 @@ _CTORS = {
     "svhn": lambda: M.FlowMatchingUNetSVHN(),
     "ratio28": lambda: M.RatioEstimator(),
     "ratio_ms": lambda: M.RatioEstimatorMNISTSVHN(),
+    "fm_original": lambda: M.FlowMatchingModel(),
     "clf_mnist": lambda: __import__("ratio_guided_multimodal_fm_amd.models.svhn_classifier", fromlist=["x"]).MNISTClassifier32(),
     "clf_svhn": lambda: __import__("ratio_guided_multimodal_fm_amd.models.svhn_classifier", fromlist=["x"]).SVHNClassifier(),
 }
