@@ -159,6 +159,42 @@ int rgfm_sample_pair(rgfm_unet* hx, rgfm_unet* hy, float* x_inout, float* y_inou
                      int batch, int num_steps, double gamma, int step_begin, int step_end, void* ws,
                      size_t ws_bytes, rgfm_stream_t stream);
 
+/* ------------------------------------------------------------------ FlowMatchingModel ("--model original")
+ * The reference's encoder-decoder velocity net (src/models/flow_matching.py:127-173;
+ * built by src/sample.py:152-154 and src/evaluate.py:144-146) for 1x28x28 images:
+ * ImageEncoder (:34-72: four 3x3 convs, two of them stride 2, GroupNorm(8)+SiLU,
+ * Linear 12544->feature_dim), SinusoidalPositionEmbeddings (:11-31) and
+ * VelocityDecoder (:75-124: Linear, two ConvTranspose2d(k4,s2,p1), 3x3 convs).
+ * Same conventions as rgfm_unet_*: blob = state_dict() order, NCHW boundary tensors,
+ * caller-owned workspace, stream-ordered, no synchronisation. */
+typedef struct rgfm_fmnet_desc {
+  int32_t img_channels; /* 1   (FlowMatchingModel.__init__ argument, :138) */
+  int32_t feature_dim;  /* 256 */
+  int32_t time_emb_dim; /* 128 */
+} rgfm_fmnet_desc;
+
+typedef struct rgfm_fmnet rgfm_fmnet;
+
+int rgfm_fmnet_param_floats(const rgfm_fmnet_desc* desc, size_t* n_floats);
+int rgfm_fmnet_create(const rgfm_fmnet_desc* desc, const float* params_dev, size_t n_floats,
+                      rgfm_stream_t stream, rgfm_fmnet** out);
+void rgfm_fmnet_destroy(rgfm_fmnet* h);
+/* bytes for one forward or one rgfm_fmnet_sample_single call at this batch */
+int rgfm_fmnet_workspace_bytes(const rgfm_fmnet* h, int batch, size_t* bytes);
+/* v_out[B,1,28,28] = model(x, t)  (FlowMatchingModel.forward, :153-173); t_count in {1, batch} */
+int rgfm_fmnet_forward(rgfm_fmnet* h, const float* x, const float* t_dev, int t_count, float* v_out,
+                       int batch, void* ws, size_t ws_bytes, rgfm_stream_t stream);
+/* CFMSchedule.sample / the unguided Euler loops of flow_utils.py:69-100, :186-278 with this net */
+int rgfm_fmnet_sample_single(rgfm_fmnet* h, float* x_inout, int batch, int num_steps, int step_begin,
+                             int step_end, void* ws, size_t ws_bytes, rgfm_stream_t stream);
+/* paired_sampler (flow_utils.py:186-278) with two FlowMatchingModel nets: as rgfm_sample_pair */
+int rgfm_fmnet_sample_pair_workspace_bytes(const rgfm_fmnet* hx, const rgfm_fmnet* hy, int batch,
+                                           int n_mc, size_t* bytes);
+int rgfm_fmnet_sample_pair(rgfm_fmnet* hx, rgfm_fmnet* hy, float* x_inout, float* y_inout,
+                           const float* mc_x1, const float* mc_y1, const float* mc_ratios, int n_mc,
+                           int batch, int num_steps, double gamma, int step_begin, int step_end,
+                           void* ws, size_t ws_bytes, rgfm_stream_t stream);
+
 /* One guidance evaluation on its own (parity hook for sample_mnist_svhn.py:124-171):
  * vx/vy are overwritten with (1-gamma)*v + gamma*g at time t; weights_out[B,N]
  * (optional, may be null) receives the normalised importance weights. */

@@ -88,18 +88,19 @@ class _EngineBase:
                 "semantics only (Dropout = identity, BatchNorm = running statistics). Call .eval().")
 
 
-class UNetEngine(_EngineBase):
+class _VelocityEngine(_EngineBase):
+    """Shared handle cache / forward of the velocity nets; subclasses name the ABI family."""
+    PREFIX = None          # rgfm_<family>_{param_floats,create,destroy,workspace_bytes,forward}
+    SINGLE = SINGLE_WS = PAIR = PAIR_WS = None
+
     def desc(self):
-        m = self._module()
-        d = _lib.UNetDesc()
-        d.in_channels, d.img_size, d.model_channels = m.in_channels, m.img_size, m.model_channels
-        d.num_levels = len(m.channel_mult)
-        if d.num_levels > 4:
-            raise _lib.RgfmError("at most 4 resolution levels are supported")
-        for i, c in enumerate(m.channel_mult):
-            d.channel_mult[i] = c
-        d.num_res_blocks = m.num_res_blocks
-        return d
+        raise NotImplementedError
+
+    def _check_input(self, m, x):
+        raise NotImplementedError
+
+    def _fn(self, name):
+        return getattr(_lib.lib(), f"{self.PREFIX}_{name}")
 
     def handle(self, device):
         m = self._module()
@@ -107,24 +108,23 @@ class UNetEngine(_EngineBase):
         key = self._state_key(sd)
         if self._handle is not None and key == self._key:
             return self._handle
-        L = _lib.lib()
         if self._handle is not None:
             self._destroy()
         d = self.desc()
         n = ctypes.c_size_t()
-        _lib.check(L.rgfm_unet_param_floats(ctypes.byref(d), ctypes.byref(n)))
+        _lib.check(self._fn("param_floats")(ctypes.byref(d), ctypes.byref(n)))
         blob = self._blob_from(sd, device)
         if blob.numel() != n.value:
             raise _lib.RgfmError(f"parameter blob has {blob.numel()} floats, library expects {n.value}")
         h = ctypes.c_void_p()
         with torch.cuda.device(device):
-            _lib.check(L.rgfm_unet_create(ctypes.byref(d), _ptr(blob), blob.numel(), _stream(device),
+            _lib.check(self._fn("create")(ctypes.byref(d), _ptr(blob), blob.numel(), _stream(device),
                                           ctypes.byref(h)))
         self._handle, self._key, self._blob = h, key, blob
         return h
 
     def _destroy(self):
-        _lib.lib().rgfm_unet_destroy(self._handle)
+        self._fn("destroy")(self._handle)
         self._handle = None
 
     def workspace(self, fn_name, batch, device):
@@ -137,8 +137,7 @@ class UNetEngine(_EngineBase):
         m = self._module()
         self._check_eval(m)
         _require_hip(x, t)
-        if x.dim() != 4 or x.shape[1] != m.in_channels or x.shape[2] != m.img_size or x.shape[3] != m.img_size:
-            raise _lib.RgfmError(f"expected x of shape [B,{m.in_channels},{m.img_size},{m.img_size}], got {tuple(x.shape)}")
+        self._check_input(m, x)
         B = x.shape[0]
         t = t.reshape(-1)
         if t.numel() not in (1, B):
@@ -151,10 +150,49 @@ class UNetEngine(_EngineBase):
         dev = x.device
         with torch.cuda.device(dev):
             h = self.handle(dev)
-            ws, nb = self.workspace("rgfm_unet_workspace_bytes", B, dev)
-            _lib.check(_lib.lib().rgfm_unet_forward(h, _ptr(x), _ptr(t), t.numel(), _ptr(out), B,
-                                                    _ptr(ws), nb, _stream(dev)))
+            ws, nb = self.workspace(f"{self.PREFIX}_workspace_bytes", B, dev)
+            _lib.check(self._fn("forward")(h, _ptr(x), _ptr(t), t.numel(), _ptr(out), B, _ptr(ws), nb,
+                                           _stream(dev)))
         return out
+
+
+class FmNetEngine(_VelocityEngine):
+    """FlowMatchingModel ('--model original', reference src/models/flow_matching.py:127-173)."""
+    PREFIX = "rgfm_fmnet"
+    SINGLE, SINGLE_WS = "rgfm_fmnet_sample_single", "rgfm_fmnet_workspace_bytes"
+    PAIR, PAIR_WS = "rgfm_fmnet_sample_pair", "rgfm_fmnet_sample_pair_workspace_bytes"
+
+    def desc(self):
+        m = self._module()
+        d = _lib.FmNetDesc()
+        d.img_channels, d.feature_dim, d.time_emb_dim = m.img_channels, m.feature_dim, m.time_emb_dim
+        return d
+
+    def _check_input(self, m, x):
+        if x.dim() != 4 or tuple(x.shape[1:]) != (m.img_channels, 28, 28):
+            raise _lib.RgfmError(f"expected x of shape [B,{m.img_channels},28,28], got {tuple(x.shape)}")
+
+
+class UNetEngine(_VelocityEngine):
+    PREFIX = "rgfm_unet"
+    SINGLE, SINGLE_WS = "rgfm_sample_single", "rgfm_sample_single_workspace_bytes"
+    PAIR, PAIR_WS = "rgfm_sample_pair", "rgfm_sample_pair_workspace_bytes"
+
+    def _check_input(self, m, x):
+        if x.dim() != 4 or x.shape[1] != m.in_channels or x.shape[2] != m.img_size or x.shape[3] != m.img_size:
+            raise _lib.RgfmError(f"expected x of shape [B,{m.in_channels},{m.img_size},{m.img_size}], got {tuple(x.shape)}")
+
+    def desc(self):
+        m = self._module()
+        d = _lib.UNetDesc()
+        d.in_channels, d.img_size, d.model_channels = m.in_channels, m.img_size, m.model_channels
+        d.num_levels = len(m.channel_mult)
+        if d.num_levels > 4:
+            raise _lib.RgfmError("at most 4 resolution levels are supported")
+        for i, c in enumerate(m.channel_mult):
+            d.channel_mult[i] = c
+        d.num_res_blocks = m.num_res_blocks
+        return d
 
     # ---- parity hooks -------------------------------------------------
     def forward_trace(self, x, t):
@@ -264,9 +302,9 @@ def sample_single(model, x, num_steps, step_begin=0, step_end=None):
         return x
     with torch.cuda.device(dev):
         h = eng.handle(dev)
-        ws, nb = eng.workspace("rgfm_sample_single_workspace_bytes", B, dev)
-        _lib.check(_lib.lib().rgfm_sample_single(h, _ptr(x), B, int(num_steps), int(step_begin),
-                                                 int(step_end), _ptr(ws), nb, _stream(dev)))
+        ws, nb = eng.workspace(eng.SINGLE_WS, B, dev)
+        _lib.check(getattr(_lib.lib(), eng.SINGLE)(h, _ptr(x), B, int(num_steps), int(step_begin),
+                                                   int(step_end), _ptr(ws), nb, _stream(dev)))
     return x
 
 
@@ -301,6 +339,10 @@ def sample_pair(fm_x, fm_y, x, y, mc_x1, mc_y1, mc_ratios, num_steps, gamma, ste
     """In-place paired Euler loop with optional MC guidance (rgfm_sample_pair)."""
     for m in (fm_x, fm_y):
         m._engine._check_eval(m)
+    ex = fm_x._engine
+    if type(ex) is not type(fm_y._engine):
+        raise _lib.RgfmError("paired sampling needs two velocity nets of the same family "
+                             f"(got {type(fm_x).__name__} and {type(fm_y).__name__})")
     _require_hip(x, y, mc_x1, mc_y1, mc_ratios)
     if not (x.is_contiguous() and y.is_contiguous()):
         raise _lib.RgfmError("x and y must be contiguous (they are updated in place)")
@@ -316,9 +358,9 @@ def sample_pair(fm_x, fm_y, x, y, mc_x1, mc_y1, mc_ratios, num_steps, gamma, ste
     with torch.cuda.device(dev):
         hx, hy = fm_x._engine.handle(dev), fm_y._engine.handle(dev)
         nb = ctypes.c_size_t()
-        _lib.check(L.rgfm_sample_pair_workspace_bytes(hx, hy, B, n_mc, ctypes.byref(nb)))
+        _lib.check(getattr(L, ex.PAIR_WS)(hx, hy, B, n_mc, ctypes.byref(nb)))
         ws = _sampler_ws.get(nb.value, dev)
-        _lib.check(L.rgfm_sample_pair(hx, hy, _ptr(x), _ptr(y), _ptr(mc_x1 if n_mc else None),
+        _lib.check(getattr(L, ex.PAIR)(hx, hy, _ptr(x), _ptr(y), _ptr(mc_x1 if n_mc else None),
                                       _ptr(mc_y1 if n_mc else None),
                                       _ptr(mc_ratios if n_mc else None), n_mc, B, int(num_steps),
                                       float(gamma), int(step_begin), int(step_end), _ptr(ws),

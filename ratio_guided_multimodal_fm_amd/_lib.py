@@ -27,6 +27,10 @@ class RatioDesc(ctypes.Structure):
                 ("loss_type", c_int32)]
 
 
+class FmNetDesc(ctypes.Structure):
+    _fields_ = [("img_channels", c_int32), ("feature_dim", c_int32), ("time_emb_dim", c_int32)]
+
+
 # name -> (restype, argtypes); every symbol include/rgfm.h declares.
 SIGNATURES = {
     "rgfm_unet_param_floats": (c_int, [P(UNetDesc), P(c_size_t)]),
@@ -52,6 +56,18 @@ SIGNATURES = {
     "rgfm_sample_pair": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_int, c_int, c_int, c_double, c_int, c_int, c_void_p,
                                  c_size_t, c_void_p]),
+    "rgfm_fmnet_param_floats": (c_int, [P(FmNetDesc), P(c_size_t)]),
+    "rgfm_fmnet_create": (c_int, [P(FmNetDesc), c_void_p, c_size_t, c_void_p, P(c_void_p)]),
+    "rgfm_fmnet_destroy": (None, [c_void_p]),
+    "rgfm_fmnet_workspace_bytes": (c_int, [c_void_p, c_int, P(c_size_t)]),
+    "rgfm_fmnet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                   c_size_t, c_void_p]),
+    "rgfm_fmnet_sample_single": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                         c_size_t, c_void_p]),
+    "rgfm_fmnet_sample_pair_workspace_bytes": (c_int, [c_void_p, c_void_p, c_int, c_int, P(c_size_t)]),
+    "rgfm_fmnet_sample_pair": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_int, c_int, c_int, c_double, c_int, c_int, c_void_p,
+                                       c_size_t, c_void_p]),
     "rgfm_guidance_workspace_bytes": (c_int, [c_int, c_int, P(c_size_t)]),
     "rgfm_guidance_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int, c_int, c_int, c_int, c_double, c_double,

@@ -248,11 +248,14 @@ constexpr int MAXIT = 7;  // ceil(max halo_px * 4 / 256): halo_px <= 448 in thes
 
 template <int NT, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_mfma_pf_kernel(const ConvArgs a) {
-  constexpr int NB = (9 * 32 * NT * 4 + 255) / 256;  // weight float4 items per thread
+  // CONV_T2: one output-parity class (blockIdx.z) of a ConvTranspose2d(k=4, s=2, p=1): a 2x2-tap conv on
+  // the input raster whose result lands on every other pixel of the 2H x 2W output.
+  constexpr int NTAPS = (MODE == CONV_T2) ? 4 : 9;
+  constexpr int NB = (NTAPS * 32 * NT * 4 + 255) / 256;  // weight float4 items per thread
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;
   float* sB = smem + a.halo_px * LDP;
-  float* sAB = sB + 9 * 32 * NT * LDP;  // [spt][16][2] scale/shift of the chunk being committed
+  float* sAB = sB + NTAPS * 32 * NT * LDP;  // [spt][16][2] scale/shift of the chunk being committed
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31p = lane & 31, hp_ = lane >> 5;
@@ -268,6 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pf_kernel(const ConvArgs a) 
     row0 = 0;
   }
   const int n0 = blockIdx.y * (32 * NT);
+  const int pc = (MODE == CONV_T2) ? (int)blockIdx.z : 0, py = pc >> 1, px = pc & 1;
   const int HR = g.th + 2, WR = W + 2;
   int rows_valid = H - row0;
   if (rows_valid > g.th) rows_valid = g.th;
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pf_kernel(const ConvArgs a) 
         const int b = b0 + s;
         int y, x;
         bool ok;
-        if (MODE == CONV_S1) {
+        if (MODE == CONV_S1 || MODE == CONV_T2) {
           y = row0 + hy - 1, x = hx - 1;
           ok = (y >= 0) && (y < H) && (x >= 0) && (x < W);
         } else {
@@ -401,8 +405,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pf_kernel(const ConvArgs a) 
 #pragma unroll
     for (int j = 0; j < MAXIT; ++j) ra[j] = *(const pf_gf32x4*)(src + (size_t)poff[j] * cs + cc + q4 * 4);
     const float* wsrc = skip ? a.wskip + ((size_t)(blockIdx.y * nch_skip + (ch - nch_main))) * (32 * NT * KC)
-                             : a.wpk + ((size_t)(blockIdx.y * nch_main + ch) * 9) * (32 * NT * KC);
-    const int nbit = skip ? 32 * NT * 4 : 9 * 32 * NT * 4;
+                             : a.wpk + ((size_t)((pc * gridDim.y + blockIdx.y) * nch_main + ch) * NTAPS) * (32 * NT * KC);
+    const int nbit = skip ? 32 * NT * 4 : NTAPS * 32 * NT * 4;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int it = tid + 256 * j;
@@ -439,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pf_kernel(const ConvArgs a) 
         *reinterpret_cast<f32x4*>(sA + (it >> 2) * LDP + q4 * 4) = v;
       }
     }
-    const int nbit = skip ? 32 * NT * 4 : 9 * 32 * NT * 4;
+    const int nbit = skip ? 32 * NT * 4 : NTAPS * 32 * NT * 4;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int it = tid + 256 * j;
@@ -453,9 +457,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pf_kernel(const ConvArgs a) 
   for (int ch = 0; ch < ntot; ++ch) {
     const bool skip = ch >= nch_main;
     if (ch + 1 < ntot) issue(ch + 1);
-    const int tap_lo = skip ? 4 : 0, tap_hi = skip ? 5 : 9;
+    const int tap_lo = skip ? 4 : 0, tap_hi = skip ? 5 : NTAPS;
     for (int tap = tap_lo; tap < tap_hi; ++tap) {
-      const int ky = tap / 3, kx = tap - 3 * ky;
+      int ky, kx;
+      if (MODE == CONV_T2) ky = py + (tap >> 1), kx = px + (tap & 1);
+      else ky = tap / 3, kx = tap - 3 * ky;
       const int aoff = (ky * WR + kx) * LDP;
       const int boff = (skip ? 0 : tap) * (32 * NT * LDP);
       float af[2][8], bf[NT][8];
@@ -506,7 +512,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pf_kernel(const ConvArgs a) 
       const int p = 64 * wave + pl;
       const bool valid = (g.spt == 1) ? (p < nvalid) : (sample_ok && pl < HW);
       if (valid) vmask[mt] |= 1u << r;
-      const size_t pix = pix0 + ((g.spt == 1) ? p : pl);
+      size_t pix = pix0 + ((g.spt == 1) ? p : pl);
+      if (MODE == CONV_T2) {  // scatter to (2r + py, 2x + px) of the 2H x 2W raster
+        const int pp = (g.spt == 1) ? row0 * W + p : pl;
+        const int rr = pp / W, xx = pp - rr * W;
+        pix = ((size_t)bw * (2 * H) + 2 * rr + py) * (2 * W) + 2 * xx + px;
+      }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int c = n0 + nt * 32 + l31;
@@ -524,7 +535,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pf_kernel(const ConvArgs a) 
     } else {
       nw = sample_ok ? HW : 0;
     }
-    const int part = (g.spt == 1) ? (blockIdx.x - b0 * g.tps) * 4 + wave : 0;
+    // CONV_T2: the four parity classes are separate statistics parts (gn_finalize rep = 4)
+    const int nparts = (MODE == CONV_T2) ? 4 * g.nparts : g.nparts;
+    const int part = ((g.spt == 1) ? (blockIdx.x - b0 * g.tps) * 4 + wave : 0) + pc * g.nparts;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       float s = 0.f;
@@ -550,7 +563,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pf_kernel(const ConvArgs a) 
         float2 st;
         st.x = mean;
         st.y = m2;
-        *reinterpret_cast<float2*>(a.stats_out + (((size_t)bw * g.nparts + part) * a.Cout + c) * 2) = st;
+        *reinterpret_cast<float2*>(a.stats_out + (((size_t)bw * nparts + part) * a.Cout + c) * 2) = st;
       }
     }
   }
@@ -560,7 +573,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pf_kernel(const ConvArgs a) 
 static const bool g_conv_force_simple = getenv("RGFM_CONV_SIMPLE") != nullptr;
 
 size_t conv_mfma_lds_bytes(const ConvArgs& a) {
-  const int nt = (a.Cout % 64 == 0) ? 2 : 1;
+  const int nt = (a.Cout % 64 == 0) ? 2 : 1;  // (sized for 9 taps; CONV_T2 uses the first 4)
   return (size_t)(a.halo_px + 9 * 32 * nt) * LDP * sizeof(float) + 128 * sizeof(float);
 }
 
@@ -582,17 +595,24 @@ int conv_mfma_init() {
   rc |= raise_lds<2, CONV_S1>();
   rc |= raise_lds<2, CONV_S2>();
   rc |= raise_lds<2, CONV_UP2>();
+  rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_pf_kernel<1, CONV_T2>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_pf_kernel<2, CONV_T2>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   return rc;
 }
 
 void launch_conv_mfma(const ConvArgs& a, int mode, hipStream_t s) {
   const int nt = (a.Cout % 64 == 0) ? 2 : 1;
-  dim3 grid(geom_num_tiles(a.g, a.B), a.Cout / (32 * nt));
+  dim3 grid(geom_num_tiles(a.g, a.B), a.Cout / (32 * nt), mode == CONV_T2 ? 4 : 1);
   const size_t lds = conv_mfma_lds_bytes(a);
 #define LAUNCH(NTV, M) hipLaunchKernelGGL((conv_mfma_kernel<NTV, M>), grid, dim3(256), lds, s, a)
 #define LAUNCH_PF(NTV, M) hipLaunchKernelGGL((conv_mfma_pf_kernel<NTV, M>), grid, dim3(256), lds, s, a)
   const bool pf = mode != CONV_S2 && a.halo_px * 4 <= MAXIT * 256 && !g_conv_force_simple;
-  if (nt == 2) {
+  if (mode == CONV_T2) {  // prefetching kernel only (halo_px * 4 <= MAXIT * 256 is checked by the caller)
+    if (nt == 2) LAUNCH_PF(2, CONV_T2);
+    else LAUNCH_PF(1, CONV_T2);
+  } else if (nt == 2) {
     if (mode == CONV_S2) LAUNCH(2, CONV_S2);
     else if (mode == CONV_S1) { if (pf) LAUNCH_PF(2, CONV_S1); else LAUNCH(2, CONV_S1); }
     else { if (pf) LAUNCH_PF(2, CONV_UP2); else LAUNCH(2, CONV_UP2); }

@@ -128,6 +128,94 @@ void launch_linear_mfma(const float* x, const float* w, const float* b, float* y
                      rows, in, out, x_stride, y_stride);
 }
 
+// Split-K Linear whose input rows are NHWC maps flattened per sample, with the pending
+// GroupNorm scale/shift + SiLU applied on the load (ImageEncoder: fc(flatten(silu(gn4(.)))),
+// flow_matching.py:69-71, with fc.weight re-indexed to NHWC order at create time).
+// Grid (rows/64, out/64, splits); partial sums go to part[z][rows][out].
+__global__ __launch_bounds__(256) void linear_splitk_kernel(const float* x, const float* ab, int C, const float* w,
+                                                            float* part, int rows, int in, int out, int kper) {
+  __shared__ __attribute__((aligned(16))) float sA[64 * LDP];
+  __shared__ __attribute__((aligned(16))) float sB[64 * LDP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int r0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int kbeg = blockIdx.z * kper;
+  int kend = kbeg + kper;
+  if (kend > in) kend = in;
+  const int row = tid >> 2, q = tid & 3;
+  const bool rok = r0 + row < rows;
+  const float* xr = x + (size_t)(rok ? r0 + row : 0) * in + q * 4;
+  const float* abr = ab + (size_t)(rok ? r0 + row : 0) * C * 2;
+  const float* wr = w + (size_t)(n0 + row) * in + q * 4;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  f32x4 va = *reinterpret_cast<const f32x4*>(xr + kbeg);
+  f32x4 vb = *reinterpret_cast<const f32x4*>(wr + kbeg);
+  int c0 = (kbeg + q * 4) % C;
+  f32x4 e0 = *reinterpret_cast<const f32x4*>(abr + c0 * 2), e1 = *reinterpret_cast<const f32x4*>(abr + c0 * 2 + 4);
+  for (int k0 = kbeg; k0 < kend; k0 += KC) {
+    __syncthreads();
+    {
+      f32x4 v;
+      v.x = silu_f(e0.x * va.x + e0.y);
+      v.y = silu_f(e0.z * va.y + e0.w);
+      v.z = silu_f(e1.x * va.z + e1.y);
+      v.w = silu_f(e1.z * va.w + e1.w);
+      if (!rok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(sA + row * LDP + q * 4) = v;
+      *reinterpret_cast<f32x4*>(sB + row * LDP + q * 4) = vb;
+    }
+    __syncthreads();
+    const int kn = k0 + KC < kend ? k0 + KC : kbeg;  // prefetch the next chunk under the MFMAs
+    va = *reinterpret_cast<const f32x4*>(xr + kn);
+    vb = *reinterpret_cast<const f32x4*>(wr + kn);
+    c0 = (kn + q * 4) % C;
+    e0 = *reinterpret_cast<const f32x4*>(abr + c0 * 2), e1 = *reinterpret_cast<const f32x4*>(abr + c0 * 2 + 4);
+    const float* ap = sA + (wm * 32 + l31) * LDP + h * 8;
+    const float* bp = sB + (wn * 32 + l31) * LDP + h * 8;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap), a1 = *reinterpret_cast<const f32x4*>(ap + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc, 0, 0, 0);
+  }
+  const int col = n0 + wn * 32 + l31;
+  float* dst = part + (size_t)blockIdx.z * rows * out;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int orow = r0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (orow < rows) dst[(size_t)orow * out + col] = acc[r];
+  }
+}
+
+__global__ void splitk_reduce_kernel(const float* part, const float* bias, float* y, int splits, int rows, int out,
+                                     int y_stride) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= (size_t)rows * out) return;
+  const int col = i % out;
+  const size_t row = i / out;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += part[(size_t)z * rows * out + i];
+  y[row * y_stride + col] = s + bias[col];
+}
+
+void launch_linear_mfma_splitk(const float* x, const float* ab, int C, const float* w, const float* b, float* y,
+                               float* part, int splits, int rows, int in, int out, int y_stride, hipStream_t s) {
+  const int kper = ((in / KC + splits - 1) / splits) * KC;
+  hipLaunchKernelGGL(linear_splitk_kernel, dim3((rows + 63) / 64, out / 64, splits), dim3(256), 0, s, x, ab, C, w, part,
+                     rows, in, out, kper);
+  const size_t n = (size_t)rows * out;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, b, y, splits, rows,
+                     out, y_stride);
+}
+
 __device__ __forceinline__ float wsum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -781,6 +781,61 @@ extern "C" int rgfm_guidance_apply(const float* x, const float* y, float* vx, fl
   return RGFM_OK;
 }
 
+namespace {
+// Shared Euler loop of paired_sampler (src/utils/flow_utils.py:186-278 with the guidance of
+// src/sample_mnist_svhn.py:117-175): eval_x / eval_y enqueue one velocity-net evaluation of step i
+// on the given stream, writing the raw velocity (guided steps) or the fused Euler update.
+template <class EvalX, class EvalY>
+int pair_loop(EvalX&& eval_x, EvalY&& eval_y, float* x_inout, float* y_inout, const float* mc_x1,
+              const float* mc_y1, const float* mc_ratios, int n_mc, int batch, int num_steps, double gamma,
+              int step_begin, int ns, int dx, int dy, float* vx, float* vy, float* logp, hipStream_t s) {
+  const double dtd = 1.0 / (double)num_steps;
+  const float dt = (float)dtd;
+  // The two velocity nets of a step are independent (reference :119-121): the second one runs on a
+  // side stream forked from / joined back into the caller's stream every step, which fills the CUs
+  // that one net's small-grid launches (8x8 level, kernel tails) leave idle.
+  struct Side {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+  };
+  static Side sides[16];  // one per device ordinal (one process may drive several devices)
+  const char* ov = getenv("RGFM_OVERLAP");  // RGFM_OVERLAP=0: both nets on the caller's stream
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  const bool overlap = !(ov && ov[0] == '0') && dev >= 0 && dev < 16;
+  Side& sd = sides[overlap ? dev : 0];
+  if (overlap && !sd.stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming));
+  }
+  hipStream_t side = sd.stream;
+  hipEvent_t ev_fork = sd.fork, ev_join = sd.join;
+  for (int i = 0; i < ns; ++i) {
+    const double t = (double)(step_begin + i) * dtd;
+    const bool guided = n_mc > 0 && t > 1e-3;  // `t > eps` test of the reference (:124)
+    hipStream_t sy = overlap ? side : s;
+    if (overlap) {
+      HIP_TRY(hipEventRecord(ev_fork, s));
+      HIP_TRY(hipStreamWaitEvent(side, ev_fork, 0));
+    }
+    int rc = eval_y(i, sy, guided ? vy : nullptr, guided ? nullptr : y_inout, dt);
+    if (rc) return rc;
+    if (overlap) HIP_TRY(hipEventRecord(ev_join, side));
+    rc = eval_x(i, s, guided ? vx : nullptr, guided ? nullptr : x_inout, dt);
+    if (rc) return rc;
+    if (overlap) HIP_TRY(hipStreamWaitEvent(s, ev_join, 0));
+    if (guided) {
+      rc = guidance_launch(x_inout, y_inout, vx, vy, mc_x1, mc_y1, mc_ratios, batch, n_mc, dx, dy, t, gamma, logp,
+                           nullptr, x_inout, y_inout, dt, s);
+      if (rc) return rc;
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return RGFM_OK;
+}
+}  // namespace
+
 extern "C" int rgfm_sample_pair_workspace_bytes(const rgfm_unet* hx, const rgfm_unet* hy, int batch, int n_mc,
                                                 size_t* bytes) {
   if (!hx || !hy || !bytes || batch < 1 || n_mc < 0) return fail(RGFM_EINVAL, "bad argument");
@@ -823,54 +878,18 @@ extern "C" int rgfm_sample_pair(rgfm_unet* hx, rgfm_unet* hy, float* x_inout, fl
   launch_time_table(hy, nullptr, num_steps, step_begin, ns, ty, s);
   const size_t mark_x = b.off;
   const size_t mark_y = mark_x + unet_eval_bytes(hx, batch);
-  const double dtd = 1.0 / (double)num_steps;
-  const float dt = (float)dtd;
-  // The two velocity nets of a step are independent (reference :119-121): the second one runs on a
-  // side stream forked from / joined back into the caller's stream every step, which fills the CUs
-  // that one net's small-grid launches (8x8 level, kernel tails) leave idle.
-  struct Side {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-  };
-  static Side sides[16];  // one per device ordinal (one process may drive several devices)
-  const char* ov = getenv("RGFM_OVERLAP");  // RGFM_OVERLAP=0: both nets on the caller's stream
-  int dev = 0;
-  HIP_TRY(hipGetDevice(&dev));
-  const bool overlap = !(ov && ov[0] == '0') && dev >= 0 && dev < 16;
-  Side& sd = sides[overlap ? dev : 0];
-  if (overlap && !sd.stream) {
-    HIP_TRY(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming));
-  }
-  hipStream_t side = sd.stream;
-  hipEvent_t ev_fork = sd.fork, ev_join = sd.join;
-  for (int i = 0; i < ns; ++i) {
-    const double t = (double)(step_begin + i) * dtd;
-    const bool guided = n_mc > 0 && t > 1e-3;  // `t > eps` test of the reference (:124)
-    hipStream_t sy = overlap ? side : s;
-    if (overlap) {
-      HIP_TRY(hipEventRecord(ev_fork, s));
-      HIP_TRY(hipStreamWaitEvent(side, ev_fork, 0));
-    }
-    b.off = mark_y;
-    UNetRun ry{hy, batch, &b, sy, ty + (size_t)i * hy->temb_total, 0, false};
-    int rc = ry.run(y_inout, guided ? vy : nullptr, guided ? nullptr : y_inout, dt);
-    if (rc) return rc;
-    if (overlap) HIP_TRY(hipEventRecord(ev_join, side));
+  auto eval_x = [&](int i, hipStream_t st, float* v_out, float* x_state, float dt) {
     b.off = mark_x;
-    UNetRun rx{hx, batch, &b, s, tx + (size_t)i * hx->temb_total, 0, false};
-    rc = rx.run(x_inout, guided ? vx : nullptr, guided ? nullptr : x_inout, dt);
-    if (rc) return rc;
-    if (overlap) HIP_TRY(hipStreamWaitEvent(s, ev_join, 0));
-    if (guided) {
-      rc = guidance_launch(x_inout, y_inout, vx, vy, mc_x1, mc_y1, mc_ratios, batch, n_mc, dx, dy, t, gamma, logp,
-                           nullptr, x_inout, y_inout, dt, s);
-      if (rc) return rc;
-    }
-  }
-  HIP_TRY(hipGetLastError());
-  return RGFM_OK;
+    UNetRun r{hx, batch, &b, st, tx + (size_t)i * hx->temb_total, 0, false};
+    return r.run(x_inout, v_out, x_state, dt);
+  };
+  auto eval_y = [&](int i, hipStream_t st, float* v_out, float* y_state, float dt) {
+    b.off = mark_y;
+    UNetRun r{hy, batch, &b, st, ty + (size_t)i * hy->temb_total, 0, false};
+    return r.run(y_inout, v_out, y_state, dt);
+  };
+  return pair_loop(eval_x, eval_y, x_inout, y_inout, mc_x1, mc_y1, mc_ratios, n_mc, batch, num_steps, gamma,
+                   step_begin, ns, dx, dy, vx, vy, logp, s);
 }
 
 // ================================================================== ratio estimators
@@ -1147,4 +1166,333 @@ extern "C" int rgfm_ratio_eval(rgfm_ratio* h, const float* x, const float* y, fl
   r.run(x, y, out, what);
   HIP_TRY(hipGetLastError());
   return RGFM_OK;
+}
+
+// ================================================================== FlowMatchingModel ("--model original")
+// Encoder-decoder velocity net of src/models/flow_matching.py:34-173, 1x28x28 images.
+struct rgfm_fmnet {
+  rgfm_fmnet_desc d;
+  float* params = nullptr;
+  float* packed = nullptr;  // packed conv / deconv weights + re-indexed Linear weights
+  float* freqs = nullptr;
+  size_t n_params = 0, n_packed = 0;
+  size_t c1w = 0, c1b = 0;           // encoder.conv1 (reference layout, conv_in kernel)
+  size_t egw[4], egb[4];             // encoder.gn1..4
+  ConvW ec[3];                       // encoder.conv2..4
+  size_t fcw = 0, fcb = 0, fc_pk = 0;
+  size_t f1w = 0, f1b = 0, f1w_pk = 0, f1b_pk = 0;
+  ConvW d1, d2;                      // decoder.deconv1/2 (taps = 16 raw, packed per parity)
+  size_t dgw[3], dgb[3];             // decoder.gn1..3
+  ConvW c3;                          // decoder.conv3
+  size_t cow = 0, cob = 0;           // decoder.conv_out (reference layout, conv_out kernel)
+};
+
+namespace {
+
+constexpr int FM_S = 28, FM_P = 49, FM_CF = 256;  // image size; 7x7 bottleneck pixels x 256 channels
+constexpr int FM_FC_SPLITS = 14;                  // 12544/16 = 784 K-chunks = 14 x 56
+
+// state_dict order of FlowMatchingModel (flow_matching.py:43-54, :88-98, :147-151)
+size_t plan_fmnet(const rgfm_fmnet_desc& d, rgfm_fmnet* h) {
+  Cursor c, pk;
+  rgfm_fmnet t;
+  const int F = d.feature_dim, T = d.time_emb_dim;
+  auto conv = [&](int cin, int cout, int taps) {
+    ConvW w;
+    w.cin = cin, w.cout = cout, w.taps = taps;
+    w.w_raw = c.take((size_t)cout * cin * taps);
+    w.b = c.take(cout);
+    w.w_pk = pk.take((size_t)cout * cin * taps);
+    return w;
+  };
+  t.c1w = c.take((size_t)32 * d.img_channels * 9), t.c1b = c.take(32);
+  t.egw[0] = c.take(32), t.egb[0] = c.take(32);
+  const int ech[4] = {32, 64, 128, 256};
+  for (int i = 1; i < 4; ++i) {
+    t.ec[i - 1] = conv(ech[i - 1], ech[i], 9);
+    t.egw[i] = c.take(ech[i]), t.egb[i] = c.take(ech[i]);
+  }
+  t.fcw = c.take((size_t)F * FM_CF * FM_P), t.fcb = c.take(F);
+  t.fc_pk = pk.take((size_t)F * FM_CF * FM_P);
+  t.f1w = c.take((size_t)FM_CF * FM_P * (F + T)), t.f1b = c.take((size_t)FM_CF * FM_P);
+  t.f1w_pk = pk.take((size_t)FM_CF * FM_P * (F + T)), t.f1b_pk = pk.take((size_t)FM_CF * FM_P);
+  t.d1 = conv(256, 128, 16);
+  t.dgw[0] = c.take(128), t.dgb[0] = c.take(128);
+  t.d2 = conv(128, 64, 16);
+  t.dgw[1] = c.take(64), t.dgb[1] = c.take(64);
+  t.c3 = conv(64, 32, 9);
+  t.dgw[2] = c.take(32), t.dgb[2] = c.take(32);
+  t.cow = c.take((size_t)d.img_channels * 32 * 9), t.cob = c.take(d.img_channels);
+  if (h) {
+    float *pa = h->params, *pp = h->packed, *fr = h->freqs;
+    *h = t;
+    h->d = d, h->params = pa, h->packed = pp, h->freqs = fr;
+    h->n_packed = pk.off;
+  }
+  return c.off;
+}
+
+int check_fm_desc(const rgfm_fmnet_desc* d) {
+  if (!d) return fail(RGFM_EINVAL, "null descriptor");
+  if (d->img_channels != 1) return fail(RGFM_EINVAL, "FlowMatchingModel: img_channels must be 1");
+  if (d->feature_dim < 64 || d->feature_dim % 64 || d->feature_dim > 1024)
+    return fail(RGFM_EINVAL, "feature_dim must be a multiple of 64 in 64..1024");
+  if (d->time_emb_dim < 16 || d->time_emb_dim % 16 || d->time_emb_dim > 1024)
+    return fail(RGFM_EINVAL, "time_emb_dim must be a multiple of 16 in 16..1024");
+  return RGFM_OK;
+}
+
+struct FmRun {
+  rgfm_fmnet* h;
+  int B;
+  Bump* ws;
+  hipStream_t s;
+  bool dry;
+  const float* t_dev;  // explicit times (t_count 1 or B) or null: t of sampler step `step`
+  int t_count, num_steps, step;
+
+  struct Map {  // NHWC activation + GroupNorm partials; rep 4 = written by a CONV_T2 launch over an (S/2)^2 raster
+    float* data = nullptr;
+    float* stats = nullptr;
+    int C = 0, S = 0, rep = 1;
+  };
+  Map new_map(int C, int S, int rep) {
+    Map m;
+    m.C = C, m.S = S, m.rep = rep;
+    const TileGeom g = make_geom(rep == 4 ? S / 2 : S, rep == 4 ? S / 2 : S);
+    m.data = ws->f((size_t)B * S * S * C);
+    m.stats = ws->f((size_t)B * g.nparts * rep * C * 2);
+    return m;
+  }
+  float* finalize(const Map& a, size_t gamma, size_t beta) {
+    float* ab = ws->f((size_t)B * a.C * 2);
+    if (dry) return ab;
+    GnFinalizeArgs f{};
+    f.stats0 = a.stats, f.C0 = a.C, f.groups = 8;
+    f.gamma = h->params + gamma, f.beta = h->params + beta;
+    f.ab = ab, f.B = B, f.rep = a.rep;
+    const int sg = a.rep == 4 ? a.S / 2 : a.S;
+    f.g = make_geom(sg, sg);
+    ProfScope p(RGFM_KCLASS_OTHER, 0, s);
+    launch_gn_finalize(f, s);
+    return ab;
+  }
+  Map conv(const Map& a, const float* ab, const ConvW& w, int mode) {
+    const int So = mode == CONV_S2 ? (a.S + 1) / 2 : (mode == CONV_T2 ? a.S * 2 : a.S);
+    Map o = new_map(w.cout, So, mode == CONV_T2 ? 4 : 1);
+    if (dry) return o;
+    ConvArgs c{};
+    c.in0 = a.data, c.C0 = a.C, c.Hin = c.Win = a.S, c.ab = ab;
+    c.wpk = h->packed + w.w_pk, c.bias = h->params + w.b;
+    c.out = o.data, c.stats_out = o.stats, c.B = B, c.Cout = w.cout;
+    const int sg = mode == CONV_T2 ? a.S : So;  // raster the tiles walk
+    c.g = make_geom(sg, sg);
+    c.halo_px = mode == CONV_S2 ? c.g.spt * (2 * c.g.th + 1) * (2 * c.g.W + 1) : c.g.spt * (c.g.th + 2) * (c.g.W + 2);
+    const double fl = mode == CONV_T2 ? conv_flops(B, 4 * sg * sg, w.cout, 4 * w.cin) : conv_flops(B, So * So, w.cout, 9 * w.cin);
+    ProfScope p(RGFM_KCLASS_CONV_MFMA, fl, s);
+    launch_conv_mfma(c, mode, s);
+    return o;
+  }
+
+  // FlowMatchingModel.forward (flow_matching.py:153-173)
+  int run(const float* x, float* v_out, float* x_state, float dt) {
+    const int F = h->d.feature_dim, T = h->d.time_emb_dim;
+    // ImageEncoder.forward (:56-72)
+    Map cur = new_map(32, FM_S, 1);
+    if (!dry) {
+      ConvInArgs ci{};
+      ci.x = x, ci.w = h->params + h->c1w, ci.bias = h->params + h->c1b;
+      ci.out = cur.data, ci.stats_out = cur.stats, ci.B = B, ci.C0 = 32, ci.g = make_geom(FM_S, FM_S);
+      ProfScope p(RGFM_KCLASS_OTHER, 0, s);
+      launch_conv_in(ci, 1, s);
+    }
+    const int modes[3] = {CONV_S2, CONV_S2, CONV_S1};
+    for (int i = 0; i < 3; ++i) {
+      float* ab = finalize(cur, h->egw[i], h->egb[i]);
+      cur = conv(cur, ab, h->ec[i], modes[i]);
+    }
+    float* ab4 = finalize(cur, h->egw[3], h->egb[3]);
+    float* comb = ws->f((size_t)B * (F + T));  // torch.cat([features, t_emb], dim=1) (:111)
+    float* part = ws->f((size_t)FM_FC_SPLITS * B * F);
+    float* d0 = ws->f((size_t)B * FM_P * FM_CF);
+    if (!dry) {
+      ProfScope p(RGFM_KCLASS_OTHER, 0, s);
+      launch_linear_mfma_splitk(cur.data, ab4, FM_CF, h->packed + h->fc_pk, h->params + h->fcb, comb, part,
+                                FM_FC_SPLITS, B, FM_P * FM_CF, F, F + T, s);
+      launch_fm_time_embed(t_dev, t_count, num_steps, step, h->freqs, comb, B, T, F + T, F, s);
+      // VelocityDecoder.forward (:100-124); fc1 rows re-indexed so the result is the NHWC 7x7x256 map
+      launch_linear_mfma(comb, h->packed + h->f1w_pk, h->packed + h->f1b_pk, d0, B, F + T, FM_P * FM_CF, F + T,
+                         FM_P * FM_CF, s);
+    }
+    Map m0;
+    m0.data = d0, m0.C = FM_CF, m0.S = 7;
+    Map u1 = conv(m0, nullptr, h->d1, CONV_T2);
+    float* ab1 = finalize(u1, h->dgw[0], h->dgb[0]);
+    Map u2 = conv(u1, ab1, h->d2, CONV_T2);
+    float* ab2 = finalize(u2, h->dgw[1], h->dgb[1]);
+    Map u3 = conv(u2, ab2, h->c3, CONV_S1);
+    float* ab3 = finalize(u3, h->dgw[2], h->dgb[2]);
+    if (!dry) {
+      ConvOutArgs co{};
+      co.in = u3.data, co.ab = ab3, co.w = h->params + h->cow, co.bias = h->params + h->cob;
+      co.v_out = v_out, co.x_state = x_state, co.dt = dt, co.B = B, co.Cin = 32;
+      co.g = make_geom(FM_S, FM_S);
+      co.halo_px = co.g.spt * (co.g.th + 2) * (co.g.W + 2);
+      ProfScope p(RGFM_KCLASS_OTHER, 0, s);
+      launch_conv_out(co, 1, s);
+    }
+    return RGFM_OK;
+  }
+};
+
+size_t fm_eval_bytes(rgfm_fmnet* h, int B) {
+  Bump b;
+  FmRun r{h, B, &b, nullptr, true, nullptr, 1, 1, 0};
+  r.run(nullptr, nullptr, nullptr, 0.f);
+  return b.off;
+}
+
+}  // namespace
+
+extern "C" int rgfm_fmnet_param_floats(const rgfm_fmnet_desc* desc, size_t* n_floats) {
+  int rc = check_fm_desc(desc);
+  if (rc) return rc;
+  if (!n_floats) return fail(RGFM_EINVAL, "null output");
+  *n_floats = plan_fmnet(*desc, nullptr);
+  return RGFM_OK;
+}
+
+extern "C" int rgfm_fmnet_create(const rgfm_fmnet_desc* desc, const float* params_dev, size_t n_floats,
+                                 rgfm_stream_t stream, rgfm_fmnet** out) {
+  int rc = check_fm_desc(desc);
+  if (rc) return rc;
+  if (!params_dev || !out) return fail(RGFM_EINVAL, "null argument");
+  if ((rc = ensure_init())) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  rgfm_fmnet* h = new rgfm_fmnet();
+  h->n_params = plan_fmnet(*desc, h);
+  if (h->n_params != n_floats) {
+    const size_t want = h->n_params;
+    delete h;
+    return fail(RGFM_EINVAL, "parameter blob has %zu floats, architecture needs %zu", n_floats, want);
+  }
+  auto bail = [&](int code, const char* what) {
+    rgfm_fmnet_destroy(h);
+    return fail(code, "%s", what);
+  };
+  const int F = desc->feature_dim, T = desc->time_emb_dim, half = T / 2;
+  if (hipMalloc(&h->params, n_floats * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(params)");
+  if (hipMalloc(&h->packed, (h->n_packed + 4) * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(packed)");
+  if (hipMalloc(&h->freqs, half * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(freqs)");
+  if (hipMemcpyAsync(h->params, params_dev, n_floats * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return bail(RGFM_EHIP, "hipMemcpyAsync(params)");
+  for (const ConvW& w : h->ec) launch_pack_conv(h->params + w.w_raw, h->packed + w.w_pk, w.cout, w.cin, 9, nt32_of(w.cout), s);
+  launch_pack_conv(h->params + h->c3.w_raw, h->packed + h->c3.w_pk, 32, 64, 9, 1, s);
+  launch_pack_deconv(h->params + h->d1.w_raw, h->packed + h->d1.w_pk, 256, 128, nt32_of(128), s);
+  launch_pack_deconv(h->params + h->d2.w_raw, h->packed + h->d2.w_pk, 128, 64, nt32_of(64), s);
+  launch_permute_cols(h->params + h->fcw, h->packed + h->fc_pk, F, FM_CF, FM_P, s);
+  launch_permute_rows(h->params + h->f1w, h->params + h->f1b, h->packed + h->f1w_pk, h->packed + h->f1b_pk, FM_CF, FM_P,
+                      F + T, s);
+  // exp(arange(half) * -(ln(1e4) / (half - 1))) in fp32, as torch evaluates it (flow_matching.py:25-27)
+  std::vector<float> fr(half);
+  const float neg = (float)(-(std::log(10000.0) / (double)(half - 1)));
+  for (int i = 0; i < half; ++i) fr[i] = std::exp((float)i * neg);
+  if (hipMemcpy(h->freqs, fr.data(), half * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return bail(RGFM_EHIP, "hipMemcpy(freqs)");
+  *out = h;
+  return RGFM_OK;
+}
+
+extern "C" void rgfm_fmnet_destroy(rgfm_fmnet* h) {
+  if (!h) return;
+  if (h->params) (void)hipFree(h->params);
+  if (h->packed) (void)hipFree(h->packed);
+  if (h->freqs) (void)hipFree(h->freqs);
+  delete h;
+}
+
+extern "C" int rgfm_fmnet_workspace_bytes(const rgfm_fmnet* h, int batch, size_t* bytes) {
+  if (!h || !bytes || batch < 1) return fail(RGFM_EINVAL, "bad argument");
+  *bytes = fm_eval_bytes(const_cast<rgfm_fmnet*>(h), batch);
+  return RGFM_OK;
+}
+
+extern "C" int rgfm_fmnet_forward(rgfm_fmnet* h, const float* x, const float* t_dev, int t_count, float* v_out,
+                                  int batch, void* ws, size_t ws_bytes, rgfm_stream_t stream) {
+  if (!h || !x || !t_dev || !v_out || !ws) return fail(RGFM_EINVAL, "null argument");
+  if (batch < 1 || (t_count != 1 && t_count != batch)) return fail(RGFM_EINVAL, "t_count must be 1 or batch");
+  const size_t need = fm_eval_bytes(h, batch);
+  if (need > ws_bytes) return fail(RGFM_ENOMEM, "workspace too small: %zu < %zu", ws_bytes, need);
+  Bump b;
+  b.base = (char*)ws, b.cap = ws_bytes, b.dry = false;
+  FmRun r{h, batch, &b, (hipStream_t)stream, false, t_dev, t_count, 1, 0};
+  int rc = r.run(x, v_out, nullptr, 0.f);
+  if (rc) return rc;
+  HIP_TRY(hipGetLastError());
+  return RGFM_OK;
+}
+
+extern "C" int rgfm_fmnet_sample_single(rgfm_fmnet* h, float* x_inout, int batch, int num_steps, int step_begin,
+                                        int step_end, void* ws, size_t ws_bytes, rgfm_stream_t stream) {
+  if (!h || !x_inout || !ws) return fail(RGFM_EINVAL, "null argument");
+  if (batch < 1 || num_steps < 1 || step_begin < 0 || step_end > num_steps || step_begin > step_end)
+    return fail(RGFM_EINVAL, "bad step range [%d,%d) of %d", step_begin, step_end, num_steps);
+  const size_t need = fm_eval_bytes(h, batch);
+  if (need > ws_bytes) return fail(RGFM_ENOMEM, "workspace too small: %zu < %zu", ws_bytes, need);
+  const float dt = (float)(1.0 / (double)num_steps);
+  for (int st = step_begin; st < step_end; ++st) {
+    Bump b;
+    b.base = (char*)ws, b.cap = ws_bytes, b.dry = false;
+    FmRun r{h, batch, &b, (hipStream_t)stream, false, nullptr, 1, num_steps, st};
+    int rc = r.run(x_inout, nullptr, x_inout, dt);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipGetLastError());
+  return RGFM_OK;
+}
+
+extern "C" int rgfm_fmnet_sample_pair_workspace_bytes(const rgfm_fmnet* hx, const rgfm_fmnet* hy, int batch, int n_mc,
+                                                      size_t* bytes) {
+  if (!hx || !hy || !bytes || batch < 1 || n_mc < 0) return fail(RGFM_EINVAL, "bad argument");
+  const size_t d = (size_t)FM_S * FM_S;
+  size_t total = fm_eval_bytes(const_cast<rgfm_fmnet*>(hx), batch) + fm_eval_bytes(const_cast<rgfm_fmnet*>(hy), batch);
+  total += 2 * ((batch * d * 4 + 255) & ~(size_t)255);
+  total += (((size_t)batch * (n_mc > 0 ? n_mc : 1) * 4) + 255) & ~(size_t)255;
+  *bytes = total;
+  return RGFM_OK;
+}
+
+extern "C" int rgfm_fmnet_sample_pair(rgfm_fmnet* hx, rgfm_fmnet* hy, float* x_inout, float* y_inout,
+                                      const float* mc_x1, const float* mc_y1, const float* mc_ratios, int n_mc,
+                                      int batch, int num_steps, double gamma, int step_begin, int step_end, void* ws,
+                                      size_t ws_bytes, rgfm_stream_t stream) {
+  if (!hx || !hy || !x_inout || !y_inout || !ws) return fail(RGFM_EINVAL, "null argument");
+  if (n_mc < 0 || (n_mc > 0 && (!mc_x1 || !mc_y1 || !mc_ratios))) return fail(RGFM_EINVAL, "MC set missing");
+  if (batch < 1 || num_steps < 1 || step_begin < 0 || step_end > num_steps || step_begin > step_end)
+    return fail(RGFM_EINVAL, "bad step range [%d,%d) of %d", step_begin, step_end, num_steps);
+  size_t need = 0;
+  rgfm_fmnet_sample_pair_workspace_bytes(hx, hy, batch, n_mc, &need);
+  if (need > ws_bytes) return fail(RGFM_ENOMEM, "workspace too small: %zu < %zu", ws_bytes, need);
+  const int ns = step_end - step_begin;
+  if (ns == 0) return RGFM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int d = FM_S * FM_S;
+  Bump b;
+  b.base = (char*)ws, b.cap = ws_bytes, b.dry = false;
+  float* vx = b.f((size_t)batch * d);
+  float* vy = b.f((size_t)batch * d);
+  float* logp = b.f((size_t)batch * (n_mc > 0 ? n_mc : 1));
+  const size_t mark_x = b.off;
+  const size_t mark_y = mark_x + fm_eval_bytes(hx, batch);
+  auto eval_x = [&](int i, hipStream_t st, float* v_out, float* x_state, float dt) {
+    b.off = mark_x;
+    FmRun r{hx, batch, &b, st, false, nullptr, 1, num_steps, step_begin + i};
+    return r.run(x_inout, v_out, x_state, dt);
+  };
+  auto eval_y = [&](int i, hipStream_t st, float* v_out, float* y_state, float dt) {
+    b.off = mark_y;
+    FmRun r{hy, batch, &b, st, false, nullptr, 1, num_steps, step_begin + i};
+    return r.run(y_inout, v_out, y_state, dt);
+  };
+  return pair_loop(eval_x, eval_y, x_inout, y_inout, mc_x1, mc_y1, mc_ratios, n_mc, batch, num_steps, gamma, step_begin,
+                   ns, d, d, vx, vy, logp, s);
 }

@@ -67,7 +67,9 @@ __host__ __device__ inline int geom_part_count(const TileGeom& g, int part) {
   return n < 0 ? 0 : (n > 64 ? 64 : n);
 }
 
-enum ConvMode { CONV_S1 = 0, CONV_S2 = 1, CONV_UP2 = 2 };
+// CONV_T2: ConvTranspose2d(k=4, s=2, p=1) as four 2x2-tap parity-class convs over the INPUT raster
+// (ConvArgs::g describes that raster; the output is [B][2H][2W][Cout]); weights from launch_pack_deconv.
+enum ConvMode { CONV_S1 = 0, CONV_S2 = 1, CONV_UP2 = 2, CONV_T2 = 3 };
 
 struct ConvArgs {
   // input: up to two NHWC sources concatenated along C (torch.cat([h, skip], 1))
@@ -132,6 +134,7 @@ struct GnFinalizeArgs {
   float* ab;            // [B][C0+C1][2]
   int B;
   TileGeom g;
+  int rep;              // 0/1: stats0 has g.nparts parts; 4: output of a CONV_T2 launch (4 x g.nparts parts of a 4*HW-pixel map)
 };
 
 struct TimeLinear {  // one ResBlock time_mlp Linear: rows [out_off, out_off+cout) of the table
@@ -172,6 +175,15 @@ void launch_conv_out(const ConvOutArgs& a, int cimg, hipStream_t s);
 void launch_gn_finalize(const GnFinalizeArgs& a, hipStream_t s);
 void launch_time_embed(const TimeEmbedArgs& a, int nt, hipStream_t s);
 void launch_pack_conv(const float* w, float* out, int Cout, int Cin, int taps, int nt32, hipStream_t s);
+// ConvTranspose2d weight [Cin][Cout][4][4] -> [4 parity][Cout/(32 nt32)][Cin/16][4 taps][32 nt32][16]
+void launch_pack_deconv(const float* w, float* out, int Cin, int Cout, int nt32, hipStream_t s);
+// out[o][p*C + c] = w[o][c*P + p]  (Linear consuming an NCHW-flattened map, re-indexed for NHWC)
+void launch_permute_cols(const float* w, float* out, int rows, int C, int P, hipStream_t s);
+// out[(p*C + c)][k] = w[(c*P + p)][k], bias likewise  (Linear producing an NCHW-flattened map)
+void launch_permute_rows(const float* w, const float* b, float* wout, float* bout, int C, int P, int K, hipStream_t s);
+// SinusoidalPositionEmbeddings (flow_matching.py:17-31) into out[b*stride + col0 + 0..dim)
+void launch_fm_time_embed(const float* t_dev, int t_count, int num_steps, int step, const float* freqs, float* out,
+                          int B, int dim, int stride, int col0, hipStream_t s);
 void launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, hipStream_t s);
 
 // ---- ratio-estimator helpers
@@ -179,6 +191,10 @@ void launch_pool2(const float* in, const float* ab, float* out, int B, int H, in
 void launch_avgpool(const float* in, const float* ab, float* out, int B, int HW, int C, hipStream_t s);
 void launch_linear_mfma(const float* x, const float* w, const float* b, float* y, int rows, int in,
                         int out, int x_stride, int y_stride, hipStream_t s);
+// split-K variant with GroupNorm-apply + SiLU on the x load (x is an NHWC map flattened per row,
+// ab[row][k % C][2]); `part` holds splits x rows x out floats
+void launch_linear_mfma_splitk(const float* x, const float* ab, int C, const float* w, const float* b, float* y,
+                               float* part, int splits, int rows, int in, int out, int y_stride, hipStream_t s);
 void launch_layernorm_silu(float* x, const float* w, const float* b, int rows, int n, hipStream_t s);
 void launch_ratio_head(const float* x, const float* w, const float* b, float* out, int rows, int n,
                        int loss, int what, hipStream_t s);

@@ -224,6 +224,9 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const GnFinalizeArgs a
   const int b = blockIdx.x;
   const int C = a.C0 + a.C1;
   const TileGeom g = a.g;
+  const int rep = a.rep > 1 ? a.rep : 1;
+  const int nparts = g.nparts * rep;
+  const double npix = (double)g.HW * (double)rep;  // pixels per channel of the normalised map
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     const float* st;
     int cs, cc;
@@ -233,10 +236,10 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const GnFinalizeArgs a
       st = a.stats1, cs = a.C1, cc = c - a.C0;
     }
     double n = 0.0, mean = 0.0, m2 = 0.0;
-    for (int p = 0; p < g.nparts; ++p) {
-      const int np = geom_part_count(g, p);
+    for (int p = 0; p < nparts; ++p) {
+      const int np = geom_part_count(g, p % g.nparts);
       if (np == 0) continue;
-      const float2 v = *reinterpret_cast<const float2*>(st + (((size_t)b * g.nparts + p) * cs + cc) * 2);
+      const float2 v = *reinterpret_cast<const float2*>(st + (((size_t)b * nparts + p) * cs + cc) * 2);
       const double nb = (double)np, d = (double)v.x - mean, nn = n + nb;
       mean += d * nb / nn;
       m2 += (double)v.y + d * d * n * nb / nn;
@@ -255,9 +258,9 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const GnFinalizeArgs a
     double m2 = 0.0;
     for (int j = 0; j < cpg; ++j) {
       const double d = s_mean[gi * cpg + j] - gm;
-      m2 += s_m2[gi * cpg + j] + d * d * (double)g.HW;
+      m2 += s_m2[gi * cpg + j] + d * d * npix;
     }
-    const double var = m2 / ((double)cpg * (double)g.HW);
+    const double var = m2 / ((double)cpg * npix);
     s_gm[gi] = (float)gm;
     s_rstd[gi] = (float)(1.0 / sqrt(var + 1e-5));
   }
@@ -353,6 +356,88 @@ __global__ void pack_conv_kernel(const float* w, float* out, int Cout, int Cin, 
 
 void launch_pack_conv(const float* w, float* out, int Cout, int Cin, int taps, int nt32, hipStream_t s) {
   hipLaunchKernelGGL(pack_conv_kernel, dim3(256), dim3(256), 0, s, w, out, Cout, Cin, taps, 32 * nt32);
+}
+
+// ConvTranspose2d(k=4, s=2, p=1) weight [Cin][Cout][4][4] (flow_matching.py:92,96) regrouped by output
+// parity (py, px): output (2i+py, 2j+px) sums input (i+py+a-1, j+px+b-1) * w[.., 3-py-2a, 3-px-2b],
+// a, b in {0,1}.  Layout [pc][Cout/nb][Cin/16][a*2+b][nb][16].
+__global__ void pack_deconv_kernel(const float* w, float* out, int Cin, int Cout, int nb) {
+  const size_t per = (size_t)Cout * Cin * 4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < 4 * per; i += (size_t)gridDim.x * blockDim.x) {
+    const int pc = (int)(i / per);
+    size_t r = i - (size_t)pc * per;
+    const int kk = r % 16;
+    r /= 16;
+    const int n = r % nb;
+    r /= nb;
+    const int tap = r % 4;
+    r /= 4;
+    const int nch = Cin / 16;
+    const int ch = r % nch;
+    const int blk = (int)(r / nch);
+    const int co = blk * nb + n, ci = ch * 16 + kk;
+    const int ky = 3 - (pc >> 1) - 2 * (tap >> 1), kx = 3 - (pc & 1) - 2 * (tap & 1);
+    out[i] = w[(((size_t)ci * Cout + co) * 4 + ky) * 4 + kx];
+  }
+}
+
+void launch_pack_deconv(const float* w, float* out, int Cin, int Cout, int nt32, hipStream_t s) {
+  hipLaunchKernelGGL(pack_deconv_kernel, dim3(256), dim3(256), 0, s, w, out, Cin, Cout, 32 * nt32);
+}
+
+__global__ void permute_cols_kernel(const float* w, float* out, int rows, int C, int P) {
+  const size_t total = (size_t)rows * C * P;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = i % C;
+    const size_t r = i / C;
+    const int p = r % P;
+    const size_t o = r / P;
+    out[i] = w[(o * C + c) * P + p];
+  }
+}
+
+void launch_permute_cols(const float* w, float* out, int rows, int C, int P, hipStream_t s) {
+  hipLaunchKernelGGL(permute_cols_kernel, dim3(512), dim3(256), 0, s, w, out, rows, C, P);
+}
+
+__global__ void permute_rows_kernel(const float* w, const float* b, float* wout, float* bout, int C, int P, int K) {
+  const size_t total = (size_t)C * P * K;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int k = i % K;
+    const size_t r = i / K;  // destination row p*C + c
+    const int c = r % C;
+    const int p = (int)(r / C);
+    const size_t src = (size_t)c * P + p;
+    wout[i] = w[src * K + k];
+    if (k == 0) bout[r] = b[src];
+  }
+}
+
+void launch_permute_rows(const float* w, const float* b, float* wout, float* bout, int C, int P, int K, hipStream_t s) {
+  hipLaunchKernelGGL(permute_rows_kernel, dim3(512), dim3(256), 0, s, w, b, wout, bout, C, P, K);
+}
+
+// SinusoidalPositionEmbeddings.forward (flow_matching.py:22-31): out = [sin(t f_i), cos(t f_i)], f_i = exp(-i ln(1e4)/(half-1)).
+// t comes from t_dev (t_count 1 or B) or, inside a sampler, from the step index exactly as flow_utils.py:92 builds it.
+__global__ void fm_time_embed_kernel(const float* t_dev, int t_count, int num_steps, int step, const float* freqs,
+                                     float* out, int B, int dim, int stride, int col0) {
+  const int half = dim / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * half) return;
+  const int b = i / half, k = i - b * half;
+  float t;
+  if (t_dev) t = t_dev[t_count == 1 ? 0 : b];
+  else t = (float)((double)step * (1.0 / (double)num_steps));
+  const float arg = t * freqs[k];
+  out[(size_t)b * stride + col0 + k] = sinf(arg);
+  out[(size_t)b * stride + col0 + half + k] = cosf(arg);
+}
+
+void launch_fm_time_embed(const float* t_dev, int t_count, int num_steps, int step, const float* freqs, float* out,
+                          int B, int dim, int stride, int col0, hipStream_t s) {
+  const int n = B * (dim / 2);
+  hipLaunchKernelGGL(fm_time_embed_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t_dev, t_count, num_steps, step,
+                     freqs, out, B, dim, stride, col0);
 }
 
 // ------------------------------------------------------------------ layout helper (parity hook)

@@ -1,12 +1,15 @@
 """``FlowMatchingModel`` -- the reference's "original" encoder-decoder velocity net
 (``src/models/flow_matching.py:127-173``, selected by ``src/sample.py --model original``).
 
-API and parameter container only (same constructor arguments, same ``state_dict`` keys and shapes,
-so reference checkpoints load).  Its kernels (two ConvTranspose2d(k4,s2,p1) and the 12544<->256/384
-Linears) are SURVEY 8(f) row 3, not built yet: no BASELINE config uses this network.  ``forward``
-therefore raises instead of silently running PyTorch -- the package has no non-HIP compute path.
+Parameter container with the reference's constructor arguments, ``state_dict`` keys and shapes (so
+reference checkpoints load); ``forward`` and the samplers run in librgfm_hip.so (``rgfm_fmnet_*``):
+the stride-2 convs and both ConvTranspose2d(k4,s2,p1) on the MFMA implicit-GEMM conv kernel (the
+transposed convs as four 2x2-tap output-parity classes), the 12544<->256/384 Linears on the MFMA
+linear kernels with their weights re-indexed to NHWC once at handle creation.  No PyTorch compute path.
 """
 import torch.nn as nn
+
+from .._engine import FmNetEngine
 
 
 class SinusoidalPositionEmbeddings(nn.Module):
@@ -47,8 +50,8 @@ class FlowMatchingModel(nn.Module):
         self.time_embed = SinusoidalPositionEmbeddings(time_emb_dim)
         self.encoder = ImageEncoder(img_channels, feature_dim)
         self.decoder = VelocityDecoder(feature_dim, time_emb_dim, img_channels)
+        self._engine = FmNetEngine(self)
 
     def forward(self, x_t, t):
-        raise NotImplementedError(
-            "FlowMatchingModel ('--model original') has no HIP kernels yet (SURVEY 8f row 3); use "
-            "FlowMatchingUNet, which every BASELINE configuration does. There is no PyTorch fallback.")
+        """v_t [B,1,28,28] = model(x_t [B,1,28,28], t [B] or [1])  (reference :153-173)."""
+        return self._engine.forward(x_t, t)

@@ -57,7 +57,7 @@ from src.utils.flow_utils import CFMSchedule as RefCFM, sample_bimodal_guided as
 torch.set_num_threads(8)
 
 SEED_W = {"unet28": 11, "unet28_y": 12, "mnist32": 13, "svhn": 14, "ratio28": 15, "ratio_ms": 16,
-          "clf_mnist": 17, "clf_svhn": 18, "fm_original": 19}
+          "clf_mnist": 17, "clf_svhn": 18, "fm_original": 19, "fm_original_y": 20}
 N_PROBE = 256
 
 
@@ -337,6 +337,16 @@ def gen_fm_original():
         out["temb"] = n(ref.time_embed(torch.tensor([0.0, 0.01, 0.5, 0.99])))
     torch.manual_seed(22)
     out["sample"] = n(quiet(RefCFM().sample, ref, 3, 10, 'cpu'))
+    # src/sample.py --model original: two FlowMatchingModel nets + the 28x28 ratio estimator
+    refy = build(RefFMOriginal, ours.FlowMatchingModel, SEED_W["fm_original_y"])
+    rr28 = build(RefRatio28, ours.RatioEstimator, SEED_W["ratio28"])
+    B, N, S = 5, 8, 10
+    for ci, (method, gamma) in enumerate([("none", 0.0), ("mc_feng", 0.5), ("mc_feng", 2.0)]):
+        seed = 60 + ci
+        torch.manual_seed(seed)
+        xs, ys = quiet(ref_sample_28, ref, refy, rr28, method, gamma, B, S, 'cpu', N)
+        out[f"c{ci}_cfg"] = np.array([method == "mc_feng", gamma, B, N, S, seed], dtype=np.float64)
+        out[f"c{ci}_x"], out[f"c{ci}_y"] = n(xs), n(ys)
     save("fm_original", **out)
 
 

@@ -13,7 +13,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 # must match tests/golden/make_golden.py
 SEED_W = {"unet28": 11, "unet28_y": 12, "mnist32": 13, "svhn": 14, "ratio28": 15, "ratio_ms": 16,
-          "clf_mnist": 17, "clf_svhn": 18, "fm_original": 19}
+          "clf_mnist": 17, "clf_svhn": 18, "fm_original": 19, "fm_original_y": 20}
 N_PROBE = 256
 
 _CTORS = {
@@ -24,6 +24,7 @@ _CTORS = {
     "ratio28": lambda: M.RatioEstimator(),
     "ratio_ms": lambda: M.RatioEstimatorMNISTSVHN(),
     "fm_original": lambda: M.FlowMatchingModel(),
+    "fm_original_y": lambda: M.FlowMatchingModel(),
     "clf_mnist": lambda: __import__("ratio_guided_multimodal_fm_amd.models.svhn_classifier", fromlist=["x"]).MNISTClassifier32(),
     "clf_svhn": lambda: __import__("ratio_guided_multimodal_fm_amd.models.svhn_classifier", fromlist=["x"]).SVHNClassifier(),
 }
@@ -55,3 +56,25 @@ def probe_idx(numel, salt):
 
 def maxdiff(a, b):
     return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+def oracle_fm_pair(blob_x, blob_y, ratio_blob, noise, guided, gamma, steps):
+    """paired_sampler with two FlowMatchingModel nets, composed from oracle pieces
+    (reference src/utils/flow_utils.py:186-278 as driven by src/sample.py --model original)."""
+    x, y, mx, my = (None if a is None else a.numpy().copy() for a in noise)
+    dt = np.float32(1.0 / steps)
+    r = None
+    if guided:
+        for s in range(steps):
+            t = np.array([s * (1.0 / steps)], np.float32)
+            mx = mx + O.fm_forward(blob_x, mx, t) * dt
+            my = my + O.fm_forward(blob_y, my, t) * dt
+        r = O.ratio_eval("mnist28", ratio_blob, mx, my, "ratio", "disc")
+    for s in range(steps):
+        t = s * (1.0 / steps)
+        tv = np.array([t], np.float32)
+        vx, vy = O.fm_forward(blob_x, x, tv), O.fm_forward(blob_y, y, tv)
+        if guided and t > 1e-3:
+            vx, vy = O.guidance_apply(x, y, vx, vy, mx, my, r, t, gamma)[:2]
+        x, y = x + vx * dt, y + vy * dt
+    return x, y

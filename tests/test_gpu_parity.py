@@ -221,6 +221,55 @@ def test_sampler_pair_ms(dev, ci):
     assert maxdiff(ys.cpu().numpy(), g[f"c{ci}_y"]) < TOL_SAMPLER
 
 
+# ---- FlowMatchingModel ("--model original") -------------------------------------
+@pytest.mark.parametrize("B", [3, 5, 70])
+def test_fmnet_forward(dev, B):
+    """rgfm_fmnet_forward vs oracle (and the golden vectors at B=3): shared and per-row t, batch sizes
+    that leave partial 4-sample tiles at the 7x7 level and partial 64-row tiles in the Linears."""
+    m = make_module("fm_original", dev)
+    blob = O.blob_of(make_module("fm_original"))
+    x = torch.randn(B, 1, 28, 28, generator=torch.Generator().manual_seed(79 if B == 3 else B))
+    tv = torch.tensor([0.0, 0.5, 0.99]) if B == 3 else torch.rand(B, generator=torch.Generator().manual_seed(B + 1))
+    idx = list(range(B)) if B <= 9 else [0, 1, 2, 3, B - 3, B - 2, B - 1]
+    out = m(x.to(dev), tv.to(dev)).cpu().numpy()
+    assert np.isfinite(out).all()
+    assert maxdiff(out[idx], O.fm_forward(blob, x.numpy()[idx], tv.numpy()[idx])) < TOL_EVAL
+    out1 = m(x.to(dev), torch.full((1,), 0.37, device=dev)).cpu().numpy()
+    assert maxdiff(out1[idx], O.fm_forward(blob, x.numpy()[idx], np.array([0.37], np.float32))) < TOL_EVAL
+    if B == 3:
+        g = golden("fm_original")
+        assert maxdiff(out, g["v_tvec"]) < TOL_EVAL
+        assert maxdiff(out1, g["v_t037"]) < TOL_EVAL
+        assert maxdiff(m(x.to(dev), torch.full((3,), 0.37, device=dev)).cpu().numpy(), g["v_t037"]) < TOL_EVAL
+
+
+def test_fmnet_samplers(dev):
+    """CFMSchedule.sample and the paired sampler (none / mc_feng) with FlowMatchingModel nets vs golden."""
+    from ratio_guided_multimodal_fm_amd.utils.flow_utils import CFMSchedule, paired_sampler
+    g = golden("fm_original")
+    fx, fy, rr = make_module("fm_original", dev), make_module("fm_original_y", dev), make_module("ratio28", dev)
+    x0 = torch.randn(3, 1, 28, 28, generator=torch.Generator().manual_seed(22)).to(dev)
+    xs = _engine.sample_single(fx, x0.clone(), 10)
+    assert maxdiff(xs.cpu().numpy(), g["sample"]) < TOL_SAMPLER
+    x1 = x0.clone()
+    _engine.sample_single(fx, x1, 10, 0, 4)
+    _engine.sample_single(fx, x1, 10, 4, 10)
+    assert torch.equal(x1, xs)
+    out = CFMSchedule().sample(fx, 6, num_steps=5, device=dev)
+    assert out.shape == (6, 1, 28, 28) and torch.isfinite(out).all()
+    for ci in range(3):
+        guided, gamma, B, N, S, seed = g[f"c{ci}_cfg"]
+        noise = paired_noise(int(seed), int(B), int(N) if guided else 0, (1, 28, 28), (1, 28, 28))
+        xs, ys = paired_sampler(fx, fy, rr if guided else None, "mc_feng" if guided else "none", gamma, int(B),
+                                int(S), dev, int(N), (1, 28, 28), (1, 28, 28), noise=noise, verbose=False)
+        assert maxdiff(xs.cpu().numpy(), g[f"c{ci}_x"]) < TOL_SAMPLER
+        assert maxdiff(ys.cpu().numpy(), g[f"c{ci}_y"]) < TOL_SAMPLER
+    with pytest.raises(_lib.RgfmError):  # mixed families are refused, not silently mis-dispatched
+        _engine.sample_pair(fx, make_module("unet28", dev), x0.clone(), x0.clone(), None, None, None, 4, 0.0)
+    with pytest.raises(_lib.RgfmError):
+        fx(torch.zeros(2, 1, 32, 32, device=dev), torch.zeros(2, device=dev))
+
+
 def test_public_api_signatures(dev):
     """Drop-in API: reference call shapes, generator-driven noise, returns on device."""
     import ratio_guided_multimodal_fm_amd as R
