@@ -6,3 +6,4 @@ from .unet_flexible import (FlexibleUNet, FlowMatchingUNetMNIST, FlowMatchingUNe
 from .ratio_estimator import RatioEstimator  # noqa: F401
 from .ratio_flexible import RatioEstimatorMNISTSVHN  # noqa: F401
 from .svhn_classifier import MNISTClassifier32, SVHNClassifier  # noqa: F401
+from .classifier import MNISTClassifier  # noqa: F401

@@ -57,7 +57,7 @@ from src.utils.flow_utils import CFMSchedule as RefCFM, sample_bimodal_guided as
 torch.set_num_threads(8)
 
 SEED_W = {"unet28": 11, "unet28_y": 12, "mnist32": 13, "svhn": 14, "ratio28": 15, "ratio_ms": 16,
-          "clf_mnist": 17, "clf_svhn": 18, "fm_original": 19, "fm_original_y": 20}
+          "clf_mnist": 17, "clf_svhn": 18, "fm_original": 19, "fm_original_y": 20, "clf_mnist28": 21}
 N_PROBE = 256
 
 
@@ -324,6 +324,22 @@ def gen_coherence():
          num_samples=res["num_samples"])
 
 
+def gen_coherence28():
+    """MNISTClassifier (src/models/classifier.py) logits on the golden 28x28 pairs.  src/evaluate.py itself
+    cannot be imported here (it needs torchvision), so the coherence value is its :84-91 restated on the
+    reference classifier's own logits for the identity transform."""
+    from src.models.classifier import MNISTClassifier as RefMNISTClf28
+    from ratio_guided_multimodal_fm_amd.models.classifier import MNISTClassifier as OurClf28
+    clf = build(RefMNISTClf28, OurClf28, SEED_W["clf_mnist28"])
+    g = np.load(os.path.join(HERE, "sampler_pair28.npz"))
+    xs = torch.from_numpy(np.concatenate([g[f"c{i}_x"] for i in range(3)]))
+    ys = torch.from_numpy(np.concatenate([g[f"c{i}_y"] for i in range(3)]))
+    with torch.no_grad():
+        lx, ly = clf(xs), clf(ys)
+    acc = float((lx.argmax(1).numpy() == ly.argmax(1).numpy()).mean())
+    save("coherence28", logits_x=n(lx), logits_y=n(ly), coherence_acc_identity=acc, num_samples=len(xs))
+
+
 def gen_fm_original():
     """FlowMatchingModel (--model original): forward at shared and per-row t, its time embedding, and
     CFMSchedule.sample driven with it (flow_utils.py:69-100)."""
@@ -351,8 +367,8 @@ def gen_fm_original():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["embedding", "unet_layers", "ratio", "guidance", "samplers", "coherence", "fm_original"]
+    which = sys.argv[1:] or ["embedding", "unet_layers", "ratio", "guidance", "samplers", "coherence", "fm_original", "coherence28"]
     for w in which:
         {"embedding": gen_embedding, "unet_layers": gen_unet_layers, "ratio": gen_ratio,
          "guidance": gen_guidance, "samplers": gen_samplers, "coherence": gen_coherence,
-         "fm_original": gen_fm_original}[w]()
+         "fm_original": gen_fm_original, "coherence28": gen_coherence28}[w]()

@@ -13,7 +13,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 # must match tests/golden/make_golden.py
 SEED_W = {"unet28": 11, "unet28_y": 12, "mnist32": 13, "svhn": 14, "ratio28": 15, "ratio_ms": 16,
-          "clf_mnist": 17, "clf_svhn": 18, "fm_original": 19, "fm_original_y": 20}
+          "clf_mnist": 17, "clf_svhn": 18, "fm_original": 19, "fm_original_y": 20, "clf_mnist28": 21}
 N_PROBE = 256
 
 _CTORS = {
@@ -25,6 +25,7 @@ _CTORS = {
     "ratio_ms": lambda: M.RatioEstimatorMNISTSVHN(),
     "fm_original": lambda: M.FlowMatchingModel(),
     "fm_original_y": lambda: M.FlowMatchingModel(),
+    "clf_mnist28": lambda: __import__("ratio_guided_multimodal_fm_amd.models.classifier", fromlist=["x"]).MNISTClassifier(),
     "clf_mnist": lambda: __import__("ratio_guided_multimodal_fm_amd.models.svhn_classifier", fromlist=["x"]).MNISTClassifier32(),
     "clf_svhn": lambda: __import__("ratio_guided_multimodal_fm_amd.models.svhn_classifier", fromlist=["x"]).SVHNClassifier(),
 }
