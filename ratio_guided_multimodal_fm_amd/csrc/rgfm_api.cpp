@@ -184,6 +184,7 @@ struct Cursor {
 struct ConvW {  // one packed conv
   size_t w_raw = 0, b = 0;  // offsets into the params blob
   size_t w_pk = 0;          // offset into the packed buffer
+  size_t w_bx3 = 0;         // offset (bf16 elements) into the 3-plane bf16 buffer of conv_mfma_bx3.hip
   size_t w_wino = 0;        // offset into the Winograd-transformed buffer (3x3, Cout % 64 == 0 only)
   bool has_wino = false;
   int cin = 0, cout = 0, taps = 9;
@@ -215,10 +216,16 @@ bool use_v3() {
   const char* e = getenv("RGFM_CONV");
   return e && strcmp(e, "v3") == 0;
 }
+// RGFM_CONV=bx3 routes supported convs through conv_mfma_bx3.hip (fp32 operands as three exact bf16
+// planes, six bf16-MFMA products, fp32 accumulate); RGFM_CONV=f32 forces v_mfma_f32_32x32x2_f32.
+bool use_bx3() {
+  const char* e = getenv("RGFM_CONV");
+  return e && strcmp(e, "bx3") == 0;
+}
 int ensure_init() {
   if (!on_gfx950()) return fail(RGFM_ENODEVICE, "librgfm_hip needs a gfx950 (MI355X) device; none is current");
   if (!g_conv_init) {
-    if (conv_mfma_init() != 0 || conv_v3_init() != 0 || conv_wino_init() != 0)
+    if (conv_mfma_init() != 0 || conv_v3_init() != 0 || conv_wino_init() != 0 || conv_bx3_init() != 0)
       return fail(RGFM_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     int dev = 0;
     hipDeviceProp_t p;
@@ -236,6 +243,7 @@ bool use_wino() {
 
 void launch_conv(const ConvArgs& c, int mode, const float* wino, hipStream_t s) {
   if (wino && use_wino() && conv_wino_supported(c, mode)) launch_conv_wino(c, mode, wino, s);
+  else if (use_bx3() && conv_bx3_supported(c, mode)) launch_conv_bx3(c, mode, s);
   else if (use_v3() && conv_v3_supported(c, mode)) launch_conv_v3(c, mode, g_num_cus, s);
   else launch_conv_mfma(c, mode, s);
 }
@@ -249,6 +257,8 @@ struct rgfm_unet {
   float* packed = nullptr;  // packed conv weights
   float* wino = nullptr;    // Winograd-transformed 3x3 weights
   size_t n_wino = 0;
+  unsigned short* packed3 = nullptr;  // 3-plane bf16 weights (conv_mfma_bx3.hip)
+  size_t n_packed3 = 0;
   float* freqs = nullptr;
   TimeLinear* lin_dev = nullptr;
   size_t n_params = 0, n_packed = 0;
@@ -273,7 +283,7 @@ namespace {
 // is identical) and records blob offsets.  Returns the total float count.
 size_t plan_unet(const rgfm_unet_desc& d, rgfm_unet* h) {
   Cursor c;
-  Cursor pk, wk;
+  Cursor pk, wk, p3;
   const int mc = d.model_channels, temb = 4 * mc;
   std::vector<ResW> enc, mid, dec;
   std::vector<ConvW> down, up;
@@ -284,6 +294,7 @@ size_t plan_unet(const rgfm_unet_desc& d, rgfm_unet* h) {
     w.w_raw = c.take((size_t)cout * cin * taps);
     w.b = c.take(cout);
     w.w_pk = pk.take((size_t)cout * cin * taps);
+    w.w_bx3 = p3.take((size_t)cout * cin * taps * 3);
     w.has_wino = taps == 9 && cout % 64 == 0 && cin % 16 == 0;
     if (w.has_wino) w.w_wino = wk.take((size_t)cout * cin * 16);
     return w;
@@ -343,6 +354,7 @@ size_t plan_unet(const rgfm_unet_desc& d, rgfm_unet* h) {
     h->temb_total = temb_off;
     h->n_packed = pk.off;
     h->n_wino = wk.off;
+    h->n_packed3 = p3.off;
   }
   return c.off;
 }
@@ -368,6 +380,7 @@ int check_desc(const rgfm_unet_desc* d) {
 
 void pack_one(const rgfm_unet* h, const ConvW& w, hipStream_t s) {
   launch_pack_conv(h->params + w.w_raw, h->packed + w.w_pk, w.cout, w.cin, w.taps, nt32_of(w.cout), s);
+  launch_pack_conv_bx3(h->params + w.w_raw, h->packed3 + w.w_bx3, w.cout, w.cin, w.taps, nt32_of(w.cout), s);
   if (w.has_wino) launch_wino_pack(h->params + w.w_raw, h->wino + w.w_wino, w.cout, w.cin, s);
 }
 
@@ -419,6 +432,7 @@ struct UNetRun {
     c.Hin = c.Win = a.S;
     c.ab = ab;
     c.wpk = h->packed + w.w_pk;
+    c.wpk3 = h->packed3 + w.w_bx3;
     c.bias = h->params + w.b;
     c.temb = temb, c.temb_stride = h->temb_total, c.temb_per_row = temb_per_row;
     c.res_mode = res_mode;
@@ -426,7 +440,7 @@ struct UNetRun {
       c.res0 = r0->data, c.res1 = r1 ? r1->data : nullptr;
       c.R0 = r0->C, c.R1 = r1 ? r1->C : 0;
     }
-    if (res_mode == 2) c.wskip = h->packed + sk->w_pk, c.skip_bias = h->params + sk->b;
+    if (res_mode == 2) c.wskip = h->packed + sk->w_pk, c.wskip3 = h->packed3 + sk->w_bx3, c.skip_bias = h->params + sk->b;
     c.out = o.data, c.stats_out = o.stats;
     c.B = B, c.Cout = w.cout;
     c.g = make_geom(So, So);
@@ -562,6 +576,7 @@ extern "C" int rgfm_unet_create(const rgfm_unet_desc* desc, const float* params_
   if (hipMalloc(&h->params, n_floats * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(params)");
   if (hipMalloc(&h->packed, (h->n_packed + 4) * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(packed)");
   if (hipMalloc(&h->wino, (h->n_wino + 4) * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(wino)");
+  if (hipMalloc(&h->packed3, (h->n_packed3 + 8) * sizeof(unsigned short)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(packed3)");
   if (hipMemcpyAsync(h->params, params_dev, n_floats * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
     return bail(RGFM_EHIP, "hipMemcpyAsync(params)");
   for (const auto* v : {&h->enc, &h->mid, &h->dec})
@@ -595,6 +610,7 @@ extern "C" void rgfm_unet_destroy(rgfm_unet* h) {
   if (h->params) (void)hipFree(h->params);
   if (h->packed) (void)hipFree(h->packed);
   if (h->wino) (void)hipFree(h->wino);
+  if (h->packed3) (void)hipFree(h->packed3);
   if (h->freqs) (void)hipFree(h->freqs);
   if (h->lin_dev) (void)hipFree(h->lin_dev);
   delete h;
@@ -1174,8 +1190,9 @@ struct rgfm_fmnet {
   rgfm_fmnet_desc d;
   float* params = nullptr;
   float* packed = nullptr;  // packed conv / deconv weights + re-indexed Linear weights
+  unsigned short* packed3 = nullptr;  // 3-plane bf16 conv / deconv weights (conv_mfma_bx3.hip)
   float* freqs = nullptr;
-  size_t n_params = 0, n_packed = 0;
+  size_t n_params = 0, n_packed = 0, n_packed3 = 0;
   size_t c1w = 0, c1b = 0;           // encoder.conv1 (reference layout, conv_in kernel)
   size_t egw[4], egb[4];             // encoder.gn1..4
   ConvW ec[3];                       // encoder.conv2..4
@@ -1194,7 +1211,7 @@ constexpr int FM_FC_SPLITS = 14;                  // 12544/16 = 784 K-chunks = 1
 
 // state_dict order of FlowMatchingModel (flow_matching.py:43-54, :88-98, :147-151)
 size_t plan_fmnet(const rgfm_fmnet_desc& d, rgfm_fmnet* h) {
-  Cursor c, pk;
+  Cursor c, pk, p3;
   rgfm_fmnet t;
   const int F = d.feature_dim, T = d.time_emb_dim;
   auto conv = [&](int cin, int cout, int taps) {
@@ -1203,6 +1220,7 @@ size_t plan_fmnet(const rgfm_fmnet_desc& d, rgfm_fmnet* h) {
     w.w_raw = c.take((size_t)cout * cin * taps);
     w.b = c.take(cout);
     w.w_pk = pk.take((size_t)cout * cin * taps);
+    w.w_bx3 = p3.take((size_t)cout * cin * taps * 3);
     return w;
   };
   t.c1w = c.take((size_t)32 * d.img_channels * 9), t.c1b = c.take(32);
@@ -1225,9 +1243,10 @@ size_t plan_fmnet(const rgfm_fmnet_desc& d, rgfm_fmnet* h) {
   t.cow = c.take((size_t)d.img_channels * 32 * 9), t.cob = c.take(d.img_channels);
   if (h) {
     float *pa = h->params, *pp = h->packed, *fr = h->freqs;
+    unsigned short* p3p = h->packed3;
     *h = t;
-    h->d = d, h->params = pa, h->packed = pp, h->freqs = fr;
-    h->n_packed = pk.off;
+    h->d = d, h->params = pa, h->packed = pp, h->freqs = fr, h->packed3 = p3p;
+    h->n_packed = pk.off, h->n_packed3 = p3.off;
   }
   return c.off;
 }
@@ -1283,14 +1302,14 @@ struct FmRun {
     if (dry) return o;
     ConvArgs c{};
     c.in0 = a.data, c.C0 = a.C, c.Hin = c.Win = a.S, c.ab = ab;
-    c.wpk = h->packed + w.w_pk, c.bias = h->params + w.b;
+    c.wpk = h->packed + w.w_pk, c.wpk3 = h->packed3 + w.w_bx3, c.bias = h->params + w.b;
     c.out = o.data, c.stats_out = o.stats, c.B = B, c.Cout = w.cout;
     const int sg = mode == CONV_T2 ? a.S : So;  // raster the tiles walk
     c.g = make_geom(sg, sg);
     c.halo_px = mode == CONV_S2 ? c.g.spt * (2 * c.g.th + 1) * (2 * c.g.W + 1) : c.g.spt * (c.g.th + 2) * (c.g.W + 2);
     const double fl = mode == CONV_T2 ? conv_flops(B, 4 * sg * sg, w.cout, 4 * w.cin) : conv_flops(B, So * So, w.cout, 9 * w.cin);
     ProfScope p(RGFM_KCLASS_CONV_MFMA, fl, s);
-    launch_conv_mfma(c, mode, s);
+    launch_conv(c, mode, nullptr, s);
     return o;
   }
 
@@ -1384,8 +1403,13 @@ extern "C" int rgfm_fmnet_create(const rgfm_fmnet_desc* desc, const float* param
   if (hipMalloc(&h->params, n_floats * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(params)");
   if (hipMalloc(&h->packed, (h->n_packed + 4) * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(packed)");
   if (hipMalloc(&h->freqs, half * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(freqs)");
+  if (hipMalloc(&h->packed3, (h->n_packed3 + 8) * sizeof(unsigned short)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(packed3)");
   if (hipMemcpyAsync(h->params, params_dev, n_floats * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
     return bail(RGFM_EHIP, "hipMemcpyAsync(params)");
+  for (const ConvW& w : h->ec) launch_pack_conv_bx3(h->params + w.w_raw, h->packed3 + w.w_bx3, w.cout, w.cin, 9, nt32_of(w.cout), s);
+  launch_pack_conv_bx3(h->params + h->c3.w_raw, h->packed3 + h->c3.w_bx3, 32, 64, 9, 1, s);
+  launch_pack_deconv_bx3(h->params + h->d1.w_raw, h->packed3 + h->d1.w_bx3, 256, 128, nt32_of(128), s);
+  launch_pack_deconv_bx3(h->params + h->d2.w_raw, h->packed3 + h->d2.w_bx3, 128, 64, nt32_of(64), s);
   for (const ConvW& w : h->ec) launch_pack_conv(h->params + w.w_raw, h->packed + w.w_pk, w.cout, w.cin, 9, nt32_of(w.cout), s);
   launch_pack_conv(h->params + h->c3.w_raw, h->packed + h->c3.w_pk, 32, 64, 9, 1, s);
   launch_pack_deconv(h->params + h->d1.w_raw, h->packed + h->d1.w_pk, 256, 128, nt32_of(128), s);
@@ -1406,6 +1430,7 @@ extern "C" void rgfm_fmnet_destroy(rgfm_fmnet* h) {
   if (!h) return;
   if (h->params) (void)hipFree(h->params);
   if (h->packed) (void)hipFree(h->packed);
+  if (h->packed3) (void)hipFree(h->packed3);
   if (h->freqs) (void)hipFree(h->freqs);
   delete h;
 }

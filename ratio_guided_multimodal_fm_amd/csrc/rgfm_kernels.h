@@ -79,6 +79,8 @@ struct ConvArgs {
   int Hin, Win;      // spatial size of the sources
   const float* ab;   // [B][C0+C1][2] GroupNorm scale/shift (then SiLU) applied on load; null = raw
   const float* wpk;  // packed 3x3 weights  [Cout/(32NT)][Cin/16][9][32NT][16]
+  const void* wpk3;  // the same weights as three bf16 planes [..][9][32NT][3][16] (conv_mfma_bx3.hip) or null
+  const void* wskip3;
   const float* bias; // [Cout]
   const float* temb; // time-embedding add: temb[(per_row ? b : 0) * temb_stride + c]; null = none
   int temb_stride;
@@ -163,6 +165,13 @@ int conv_mfma_init();  // raises the dynamic-LDS limit of every instantiation
 bool conv_v3_supported(const ConvArgs& a, int mode);
 int conv_v3_init();
 void launch_conv_v3(const ConvArgs& a, int mode, int num_cus, hipStream_t s);
+
+// fp32 conv with operands split into three bf16 planes, on the bf16 matrix cores (conv_mfma_bx3.hip)
+bool conv_bx3_supported(const ConvArgs& a, int mode);
+int conv_bx3_init();
+void launch_conv_bx3(const ConvArgs& a, int mode, hipStream_t s);
+void launch_pack_conv_bx3(const float* w, void* out, int Cout, int Cin, int taps, int nt32, hipStream_t s);
+void launch_pack_deconv_bx3(const float* w, void* out, int Cin, int Cout, int nt32, hipStream_t s);
 
 // Winograd F(2x2,3x3) variant (conv_wino.hip) for stride-1 3x3 convs at 8/16/32 resolution, Cout % 64 == 0
 bool conv_wino_supported(const ConvArgs& a, int mode);

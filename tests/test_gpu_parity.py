@@ -330,7 +330,7 @@ def test_full_size_properties(dev):
     assert maxdiff(ya[rows].cpu().numpy(), oy) < TOL_SAMPLER
 
 
-@pytest.mark.parametrize("env", [{"RGFM_WINO": "1"}, {"RGFM_CONV": "v3"}])
+@pytest.mark.parametrize("env", [{"RGFM_WINO": "1"}, {"RGFM_CONV": "v3"}, {"RGFM_CONV": "bx3"}])
 @pytest.mark.parametrize("tag,B", [("svhn", 5), ("mnist32", 3)])
 def test_experimental_conv_variants_keep_parity(dev, env, tag, B, monkeypatch):
     """The opt-in conv variants (Winograd F(2x2,3x3): RGFM_WINO=1; persistent one-block-per-CU kernel:
