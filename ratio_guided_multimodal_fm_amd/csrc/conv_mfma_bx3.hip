@@ -22,9 +22,6 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int RB = 112;         // bytes per LDS record
-constexpr int BX_MAXIT = 7;     // halo items per thread (halo_px <= 448)
-
 // exact 3-way bf16 split of two floats: planes h, m, l as packed bf16 pairs
 __device__ __forceinline__ void split2(float a, float b, unsigned& ph, unsigned& pm, unsigned& pl) {
   f32x2 v = {a, b};
@@ -37,56 +34,96 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& ph, unsigned&
   pl = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 
-template <int NT, int MODE>
-__global__ __launch_bounds__(256, 1) void conv_mfma_bx3_kernel(const ConvArgs a) {
+// ------------------------------------------------------------------------------------
+// Workgroup = 512 threads = 2 waves per SIMD (one wave alone cannot keep the bf16 MFMA pipe issuing
+// back to back), built as TWO of conv_mfma_pf_kernel's 4-wave tiles sharing one operand in LDS:
+//   PAIRN  (Cout % (64 NT) == 0): one 256-pixel tile x two adjacent 32NT-channel groups -- the
+//          activation halo (the expensive GroupNorm+SiLU+split staging) is staged once for both;
+//   !PAIRN: two consecutive 256-pixel tiles x one channel group -- the weights are staged once.
+// LDS records are unpadded (96 B) with the two 16-byte halves of a plane swapped on odd groups of
+// 8 records, which keeps ds_read_b128 conflict-free for 16 consecutive records.
+// ------------------------------------------------------------------------------------
+#ifdef RGFM_BX3_PROF
+__device__ unsigned long long g_bx3_prof[8];  // prologue, issue, mfma, commit-wait, commit-A, commit-B, epilogue, blocks
+#define PROF_T(var) const long long var = clock64()
+#define PROF_ADD(slot, t0, t1) prof_acc[slot] += (t1) - (t0)
+#else
+#define PROF_T(var)
+#define PROF_ADD(slot, t0, t1)
+#endif
+
+constexpr int RW = 96;
+__device__ __forceinline__ int swz(int rec, int half) { return ((half ^ (rec >> 3)) & 1) * 16; }
+
+template <int NT, int MODE, bool PAIRN>
+__global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a, const int num_tiles) {
   constexpr int NTAPS = (MODE == CONV_T2) ? 4 : 9;
-  constexpr int NBI = NTAPS * 32 * NT * 6;     // 16-byte weight items per chunk (96 B per (tap, channel))
-  constexpr int NB = (NBI + 255) / 256;
+  constexpr int NG = PAIRN ? 2 : 1;            // channel groups per block
+  constexpr int NA = PAIRN ? 1 : 2;            // pixel tiles per block
+  constexpr int NBLK = 32 * NT;                // channels per group
+  constexpr int NBIG = NTAPS * NBLK * 6;       // 16-byte weight items per chunk and group
+  constexpr int NB = (NBIG * NG + 511) / 512;
+  constexpr int MAXIT = (NA * 448 * 4 + 511) / 512;
   extern __shared__ __attribute__((aligned(16))) char smem3[];
+#ifdef RGFM_BX3_PROF
+  long long prof_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
+  PROF_T(tp0);
   char* sA = smem3;
-  char* sB = smem3 + a.halo_px * RB;
-  float* sAB = reinterpret_cast<float*>(sB + NTAPS * 32 * NT * RB);
+  char* sB = smem3 + NA * a.halo_px * RW;
+  float* sAB = reinterpret_cast<float*>(sB + NTAPS * NBLK * NG * RW);  // [NA * spt][16][2]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2, seg = wave & 3;
   const int l31p = lane & 31, hp_ = lane >> 5;
   const TileGeom g = a.g;
   const int W = g.W, H = g.H, HW = g.HW;
 
+  auto tile_origin = [&](int tile, int& b0, int& row0) {
+    if (tile >= num_tiles) {
+      b0 = a.B, row0 = 0;  // idle half of the last block: every sample index is out of range
+    } else if (g.spt == 1) {
+      b0 = tile / g.tps;
+      row0 = (tile - b0 * g.tps) * g.th;
+    } else {
+      b0 = tile * g.spt;
+      row0 = 0;
+    }
+  };
+  const int my_tile = PAIRN ? (int)blockIdx.x : (int)blockIdx.x * 2 + grp;
+  const int my_cb = PAIRN ? (int)blockIdx.y * 2 + grp : (int)blockIdx.y;
   int b0, row0;
-  if (g.spt == 1) {
-    b0 = blockIdx.x / g.tps;
-    row0 = (blockIdx.x - b0 * g.tps) * g.th;
-  } else {
-    b0 = blockIdx.x * g.spt;
-    row0 = 0;
-  }
-  const int n0 = blockIdx.y * (32 * NT);
+  tile_origin(my_tile, b0, row0);
+  const int n0 = my_cb * NBLK;
   const int pc = (MODE == CONV_T2) ? (int)blockIdx.z : 0, py = pc >> 1, px = pc & 1;
   const int HR = g.th + 2, WR = W + 2;
   int rows_valid = H - row0;
   if (rows_valid > g.th) rows_valid = g.th;
   const int nvalid = rows_valid * W;
 
-  int abase[2];
+  int arec[2];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
-    const int p = 64 * wave + 32 * mt + l31p;
+    const int p = 64 * seg + 32 * mt + l31p;
     int s, q;
     if (g.spt == 1) {
       s = 0;
       q = p < nvalid ? p : nvalid - 1;
     } else {
-      s = wave;
+      s = seg;
       q = (p & 63) < HW ? (p & 63) : HW - 1;
     }
     const int r = q / W, x = q - r * W;
-    abase[mt] = ((s * HR + r) * WR + x) * RB + hp_ * 16;
+    arec[mt] = (PAIRN ? 0 : grp) * a.halo_px + (s * HR + r) * WR + x;
   }
   int bbase[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) bbase[nt] = (nt * 32 + l31p) * RB + hp_ * 16;
+  for (int nt = 0; nt < NT; ++nt) {
+    const int rec = (PAIRN ? grp : 0) * NBLK + nt * 32 + l31p;
+    bbase[nt] = rec * RW + swz(rec, hp_);  // NBLK * NG is a multiple of 16: the swap bit does not depend on the tap
+  }
 
-  const int bw = (g.spt == 1) ? b0 : b0 + wave;
+  const int bw = (g.spt == 1) ? b0 : b0 + seg;
   const bool sample_ok = bw < a.B;
   const size_t pix0 = (g.spt == 1) ? (size_t)b0 * HW + (size_t)row0 * W : (size_t)bw * HW;
   f32x16 acc[2][NT];
@@ -106,9 +143,9 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_bx3_kernel(const ConvArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int pl = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hp_;
-          const int p = 64 * wave + pl;
-          const bool valid = (g.spt == 1) ? (p < nvalid) : (sample_ok && pl < HW);
-          const size_t pix = valid ? pix0 + ((g.spt == 1) ? p : pl) : (sample_ok ? pix0 : 0);
+          const int p = 64 * seg + pl;
+          const bool valid = (g.spt == 1) ? (sample_ok && p < nvalid) : (sample_ok && pl < HW);
+          const size_t pix = valid ? pix0 + ((g.spt == 1) ? p : pl) : 0;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] = a.res0[pix * a.Cout + n0 + nt * 32 + l31p];
         }
@@ -128,42 +165,59 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_bx3_kernel(const ConvArgs a)
     }
   }
 
-  // ---- per-item decode, once: source pixel offset, validity bit, sample index
+  // ---- per-item decode, once: source pixel offset, LDS destination, validity bit, scale/shift slot
   const int q4 = tid & 3;
   const int nA = a.halo_px * 4;
-  int poff[BX_MAXIT];
-  unsigned okmask = 0u, smask = 0u;
+  int poff[MAXIT], adst[MAXIT];
+  unsigned okmask = 0u, inmask = 0u, smask = 0u;
   {
     const int per = HR * WR;
 #pragma unroll
-    for (int j = 0; j < BX_MAXIT; ++j) {
-      const int it = tid + 256 * j;
-      poff[j] = 0;
-      if (it < nA) {
-        const int hp = it >> 2;
+    for (int j = 0; j < MAXIT; ++j) {
+      const int it = tid + 512 * j;
+      poff[j] = 0, adst[j] = 0;
+      if (it < NA * nA) {
+        const int ga = (NA == 2 && it >= nA) ? 1 : 0;
+        const int ita = it - ga * nA;
+        int tb0, trow0;
+        tile_origin(PAIRN ? (int)blockIdx.x : (int)blockIdx.x * 2 + ga, tb0, trow0);
+        const int hp = ita >> 2;
         const int s = hp / per;
         const int rem = hp - s * per;
         const int hy = rem / WR, hx = rem - hy * WR;
-        const int b = b0 + s;
+        const int b = tb0 + s;
         int y, x;
         bool ok;
         if (MODE == CONV_S1 || MODE == CONV_T2) {
-          y = row0 + hy - 1, x = hx - 1;
+          y = trow0 + hy - 1, x = hx - 1;
           ok = (y >= 0) && (y < H) && (x >= 0) && (x < W);
         } else {
-          const int yu = row0 + hy - 1, xu = hx - 1;
+          const int yu = trow0 + hy - 1, xu = hx - 1;
           ok = (yu >= 0) && (yu < H) && (xu >= 0) && (xu < W);
           y = yu >> 1, x = xu >> 1;
         }
         ok = ok && (b < a.B);
+        const int rec = ga * a.halo_px + hp;
+        adst[j] = rec * RW + swz(rec, q4 >> 1) + (q4 & 1) * 8;
+        inmask |= 1u << j;
         if (ok) {
           poff[j] = (b * a.Hin + y) * a.Win + x;
           okmask |= 1u << j;
-          smask |= (unsigned)s << (2 * j);
+          smask |= (unsigned)(ga * 4 + s) << (3 * j);
         }
       }
     }
   }
+  // scale/shift table slot of this thread (tid < NA * spt * 8): sample and channel pair
+  int ab_b = -1;
+  if (tid < NA * g.spt * 8) {
+    const int slot = tid >> 3;
+    const int ga = slot / g.spt, s = slot - ga * g.spt;
+    int tb0, trow0;
+    tile_origin(PAIRN ? (int)blockIdx.x : (int)blockIdx.x * 2 + ga, tb0, trow0);
+    if (tb0 + s < a.B) ab_b = tb0 + s;
+  }
+  const int ab_slot = (NA == 2 && g.spt == 1) ? (tid >> 3) * 4 : (tid >> 3);  // table index ga * 4 + s
 
   const int cin = a.C0 + a.C1;
   const int nch_main = cin / KC;
@@ -172,7 +226,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_bx3_kernel(const ConvArgs a)
   const char* wpk3 = reinterpret_cast<const char*>(a.wpk3);
   const char* wskip3 = reinterpret_cast<const char*>(a.wskip3);
 
-  f32x4 ra[BX_MAXIT], rb[NB], rab;
+  f32x4 ra[MAXIT], rb[NB], rab;
   rab = f32x4{1.f, 0.f, 1.f, 0.f};
 
   auto issue = [&](int ch) {
@@ -188,20 +242,32 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_bx3_kernel(const ConvArgs a)
       if (c < a.R0) src = a.res0, cs = a.R0, cc = c;
       else src = a.res1, cs = a.R1, cc = c - a.R0;
     }
+#if defined(BX3_EXP_NOA)
 #pragma unroll
-    for (int j = 0; j < BX_MAXIT; ++j) ra[j] = *(const bx_gf32x4*)(src + (size_t)poff[j] * cs + cc + q4 * 4);
-    // packed weights: 96 B per (tap, channel): [3 planes][16 k] bf16
-    const char* wsrc = skip ? wskip3 + ((size_t)(blockIdx.y * nch_skip + (ch - nch_main))) * (32 * NT * 96)
-                            : wpk3 + ((size_t)((pc * gridDim.y + blockIdx.y) * nch_main + ch) * NTAPS) * (32 * NT * 96);
-    const int nbit = skip ? 32 * NT * 6 : NBI;
+    for (int j = 0; j < MAXIT; ++j) ra[j] = f32x4{1.f, 1.f, 1.f, 1.f};
+#elif defined(BX3_EXP_ASMALL)
+#pragma unroll
+    for (int j = 0; j < MAXIT; ++j) ra[j] = *(const bx_gf32x4*)(src + (((size_t)poff[j] * cs + cc) & 0x3FF) + q4 * 4);  // experiment
+#else
+#pragma unroll
+    for (int j = 0; j < MAXIT; ++j) ra[j] = *(const bx_gf32x4*)(src + (size_t)poff[j] * cs + cc + q4 * 4);
+#endif
+    // packed weights: the chunk's LDS image ([tap][NG groups][NBLK channels] records of 96 B, halves
+    // pre-swapped) is contiguous in global memory (launch_pack_conv_bx3 with nb = NBLK * NG)
+    const int nbit = skip ? NBLK * NG * 6 : NBIG * NG;
+    const char* w0 = skip ? wskip3 + ((size_t)(blockIdx.y * nch_skip + (ch - nch_main))) * (NBLK * NG * 96)
+                          : wpk3 + ((size_t)((pc * gridDim.y + blockIdx.y) * nch_main + ch) * NTAPS) * (NBLK * NG * 96);
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      const int it = tid + 256 * j;
-      rb[j] = *(const bx_gf32x4*)(wsrc + (size_t)(it < nbit ? it : 0) * 16);
+      const int it = tid + 512 * j;
+#if defined(BX3_EXP_NOB)
+      rb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#else
+      rb[j] = *(const bx_gf32x4*)(w0 + (size_t)(it < nbit ? it : 0) * 16);
+#endif
     }
     if (!skip && a.ab) {
-      const bool use = tid < g.spt * 8 && b0 + (tid >> 3) < a.B;
-      const size_t o = use ? ((size_t)(b0 + (tid >> 3)) * cin + c + 2 * (tid & 7)) * 2 : 0;
+      const size_t o = ab_b >= 0 ? ((size_t)ab_b * cin + c + 2 * (tid & 7)) * 2 : 0;
       rab = *(const bx_gf32x4*)(a.ab + o);
     }
   };
@@ -209,17 +275,19 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_bx3_kernel(const ConvArgs a)
   auto commit = [&](int ch) {
     const bool skip = ch >= nch_main;
     const bool xform = !skip && (a.ab != nullptr);
-    if (xform && tid < g.spt * 8) *reinterpret_cast<f32x4*>(sAB + tid * 4) = rab;
+    PROF_T(tc0);
+    if (xform && tid < NA * g.spt * 8) *reinterpret_cast<f32x4*>(sAB + (ab_slot * 8 + (tid & 7)) * 4) = rab;
     __syncthreads();
+    PROF_T(tc1);
+    PROF_ADD(3, tc0, tc1);
 #pragma unroll
-    for (int j = 0; j < BX_MAXIT; ++j) {
-      const int it = tid + 256 * j;
-      if (it < nA) {
+    for (int j = 0; j < MAXIT; ++j) {
+      if ((inmask >> j) & 1u) {
         f32x4 v = ra[j];
         const bool okj = (okmask >> j) & 1u;
         if (!okj) v = f32x4{0.f, 0.f, 0.f, 0.f};
         if (xform && okj) {
-          const int s = (smask >> (2 * j)) & 3u;
+          const int s = (smask >> (3 * j)) & 7u;
           const f32x4 e0 = *reinterpret_cast<const f32x4*>(sAB + (s * 16 + q4 * 4) * 2);
           const f32x4 e1 = *reinterpret_cast<const f32x4*>(sAB + (s * 16 + q4 * 4) * 2 + 4);
           v.x = silu_fast(e0.x * v.x + e0.y);
@@ -231,45 +299,55 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_bx3_kernel(const ConvArgs a)
         split2(v.x, v.y, h0, m0, l0);
         split2(v.z, v.w, h1, m1, l1);
         const u32x2 ph = {h0, h1}, pm = {m0, m1}, pl = {l0, l1};
-        char* dst = sA + (it >> 2) * RB + q4 * 8;
+        char* dst = sA + adst[j];
         *reinterpret_cast<u32x2*>(dst) = ph;
         *reinterpret_cast<u32x2*>(dst + 32) = pm;
         *reinterpret_cast<u32x2*>(dst + 64) = pl;
       }
     }
-    const int nbit = skip ? 32 * NT * 6 : NBI;
+    PROF_T(tc2);
+    PROF_ADD(4, tc1, tc2);
+    const int nbit = skip ? NBLK * NG * 6 : NBIG * NG;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      const int it = tid + 256 * j;
-      // item it = record (it / 6), 16-byte slot (it % 6) of its 96 payload bytes
-      if (it < nbit) *reinterpret_cast<f32x4*>(sB + (it / 6) * RB + (it % 6) * 16) = rb[j];
+      const int it = tid + 512 * j;
+      if (it < nbit) *reinterpret_cast<f32x4*>(sB + it * 16) = rb[j];
     }
     __syncthreads();
+    PROF_T(tc3);
+    PROF_ADD(5, tc2, tc3);
   };
 
+  PROF_T(tp1);
+  PROF_ADD(0, tp0, tp1);
   issue(0);
   commit(0);
   for (int ch = 0; ch < ntot; ++ch) {
     const bool skip = ch >= nch_main;
+    PROF_T(ti0);
     if (ch + 1 < ntot) issue(ch + 1);
+    PROF_T(ti1);
+    PROF_ADD(1, ti0, ti1);
     const int tap_lo = skip ? 4 : 0, tap_hi = skip ? 5 : NTAPS;
 #pragma unroll 1
     for (int tap = tap_lo; tap < tap_hi; ++tap) {
       int ky, kx;
       if (MODE == CONV_T2) ky = py + (tap >> 1), kx = px + (tap & 1);
       else ky = tap / 3, kx = tap - 3 * ky;
-      const int aoff = (ky * WR + kx) * RB;
-      const int boff = (skip ? 0 : tap) * (32 * NT * RB);
+      const int toff = ky * WR + kx;
+      const int boff = (skip ? 0 : tap) * (NBLK * NG * RW);
       bf16x8 af[2][3], bf[NT][3];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < 2; ++mt) {
+        const int rec = arec[mt] + toff;
+        const char* pa = sA + rec * RW + swz(rec, hp_);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) af[mt][p] = *reinterpret_cast<const bf16x8*>(sA + abase[mt] + aoff + p * 32);
+        for (int p = 0; p < 3; ++p) af[mt][p] = *reinterpret_cast<const bf16x8*>(pa + p * 32);
+      }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int p = 0; p < 3; ++p) bf[nt][p] = *reinterpret_cast<const bf16x8*>(sB + bbase[nt] + boff + p * 32);
-      // plane pairs (activation, weight), smallest products first
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
       for (int q = 0; q < 6; ++q)
@@ -279,8 +357,11 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_bx3_kernel(const ConvArgs a)
           for (int nt = 0; nt < NT; ++nt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][PA[q]], bf[nt][PB[q]], acc[mt][nt], 0, 0, 0);
     }
+    PROF_T(tm1);
+    PROF_ADD(2, ti1, tm1);
     if (ch + 1 < ntot) commit(ch + 1);
   }
+  PROF_T(te0);
 
   // ---------------------------------------------------------------- epilogue (as conv_mfma_pf_kernel)
   int lane_e = lane;
@@ -299,8 +380,8 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_bx3_kernel(const ConvArgs a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int pl = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
-      const int p = 64 * wave + pl;
-      const bool valid = (g.spt == 1) ? (p < nvalid) : (sample_ok && pl < HW);
+      const int p = 64 * seg + pl;
+      const bool valid = (g.spt == 1) ? (sample_ok && p < nvalid) : (sample_ok && pl < HW);
       if (valid) vmask[mt] |= 1u << r;
       size_t pix = pix0 + ((g.spt == 1) ? p : pl);
       if (MODE == CONV_T2) {
@@ -320,13 +401,14 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_bx3_kernel(const ConvArgs a)
   if (a.stats_out) {
     int nw;
     if (g.spt == 1) {
-      nw = nvalid - 64 * wave;
+      nw = nvalid - 64 * seg;
       nw = nw < 0 ? 0 : (nw > 64 ? 64 : nw);
+      if (!sample_ok) nw = 0;
     } else {
       nw = sample_ok ? HW : 0;
     }
     const int nparts = (MODE == CONV_T2) ? 4 * g.nparts : g.nparts;
-    const int part = ((g.spt == 1) ? (blockIdx.x - b0 * g.tps) * 4 + wave : 0) + pc * g.nparts;
+    const int part = ((g.spt == 1) ? (my_tile - b0 * g.tps) * 4 + seg : 0) + pc * g.nparts;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       float s = 0.f;
@@ -356,6 +438,14 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_bx3_kernel(const ConvArgs a)
       }
     }
   }
+#ifdef RGFM_BX3_PROF
+  PROF_T(te1);
+  PROF_ADD(6, te0, te1);
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 7; ++i) atomicAdd(&g_bx3_prof[i], (unsigned long long)prof_acc[i]);
+    atomicAdd(&g_bx3_prof[7], 1ull);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------- weight packing (exact 3-way split)
@@ -365,7 +455,8 @@ __device__ __forceinline__ void split1(float v, unsigned short& h, unsigned shor
   h = (unsigned short)(ph & 0xffffu), m = (unsigned short)(pm & 0xffffu), l = (unsigned short)(pl & 0xffffu);
 }
 
-// [Cout][Cin][taps] fp32 -> [Cout/nb][Cin/16][taps][nb][3][16] bf16
+// [Cout][Cin][taps] fp32 -> [Cout/nb][Cin/16][taps][nb][3][16] bf16, nb = channels of one workgroup
+// (bx3_block_channels): each [taps][nb] slab is the byte image of the kernel's LDS weight tile
 __global__ void pack_conv_bx3_kernel(const float* w, unsigned short* out, int Cout, int Cin, int taps, int nb) {
   const size_t total = (size_t)Cout * Cin * taps;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -381,8 +472,10 @@ __global__ void pack_conv_bx3_kernel(const float* w, unsigned short* out, int Co
     const int co = blk * nb + n, ci = ch * 16 + kk;
     unsigned short h, m, l;
     split1(w[((size_t)co * Cin + ci) * taps + tap], h, m, l);
+    // record index inside the chunk's LDS image = tap * nb + n; odd groups of 8 records hold their halves swapped
+    const int kq = kk ^ ((((tap * nb + n) >> 3) & 1) << 3);
     unsigned short* rec = out + (i / 16) * 48;
-    rec[kk] = h, rec[16 + kk] = m, rec[32 + kk] = l;
+    rec[kq] = h, rec[16 + kq] = m, rec[32 + kq] = l;
   }
 }
 
@@ -405,55 +498,74 @@ __global__ void pack_deconv_bx3_kernel(const float* w, unsigned short* out, int 
     const int ky = 3 - (pc >> 1) - 2 * (tap >> 1), kx = 3 - (pc & 1) - 2 * (tap & 1);
     unsigned short h, m, l;
     split1(w[(((size_t)ci * Cout + co) * 4 + ky) * 4 + kx], h, m, l);
+    const int kq = kk ^ ((((tap * nb + n) >> 3) & 1) << 3);
     unsigned short* rec = out + (i / 16) * 48;
-    rec[kk] = h, rec[16 + kk] = m, rec[32 + kk] = l;
+    rec[kq] = h, rec[16 + kq] = m, rec[32 + kq] = l;
   }
 }
 
-void launch_pack_conv_bx3(const float* w, void* out, int Cout, int Cin, int taps, int nt32, hipStream_t s) {
-  hipLaunchKernelGGL(pack_conv_bx3_kernel, dim3(256), dim3(256), 0, s, w, (unsigned short*)out, Cout, Cin, taps, 32 * nt32);
+// channels one workgroup covers: 128 when Cout % 128 == 0 (two 64-channel groups), else 64 or 32
+int bx3_block_channels(int Cout) { return Cout % 128 == 0 ? 128 : (Cout % 64 == 0 ? 64 : 32); }
+
+void launch_pack_conv_bx3(const float* w, void* out, int Cout, int Cin, int taps, hipStream_t s) {
+  hipLaunchKernelGGL(pack_conv_bx3_kernel, dim3(256), dim3(256), 0, s, w, (unsigned short*)out, Cout, Cin, taps,
+                     bx3_block_channels(Cout));
 }
-void launch_pack_deconv_bx3(const float* w, void* out, int Cin, int Cout, int nt32, hipStream_t s) {
-  hipLaunchKernelGGL(pack_deconv_bx3_kernel, dim3(256), dim3(256), 0, s, w, (unsigned short*)out, Cin, Cout, 32 * nt32);
+void launch_pack_deconv_bx3(const float* w, void* out, int Cin, int Cout, hipStream_t s) {
+  hipLaunchKernelGGL(pack_deconv_bx3_kernel, dim3(256), dim3(256), 0, s, w, (unsigned short*)out, Cin, Cout,
+                     bx3_block_channels(Cout));
 }
 
-static size_t bx3_lds_bytes(const ConvArgs& a, int mode) {
+static bool bx3_pairn(const ConvArgs& a) {
+  const int nt = (a.Cout % 64 == 0) ? 2 : 1;
+  return a.Cout % (64 * nt) == 0;
+}
+static size_t bx3w_lds_bytes(const ConvArgs& a, int mode) {
   const int nt = (a.Cout % 64 == 0) ? 2 : 1;
   const int ntaps = mode == CONV_T2 ? 4 : 9;
-  return (size_t)(a.halo_px + ntaps * 32 * nt) * RB + 128 * sizeof(float);
+  const bool pn = bx3_pairn(a);
+  return (size_t)((pn ? 1 : 2) * a.halo_px + ntaps * 32 * nt * (pn ? 2 : 1)) * RW + 2 * 128 * sizeof(float);
 }
-
 bool conv_bx3_supported(const ConvArgs& a, int mode) {
   if (mode == CONV_S2 || !a.wpk3) return false;
   if (a.res_mode == 2 && !a.wskip3) return false;
-  return a.halo_px * 4 <= BX_MAXIT * 256 && bx3_lds_bytes(a, mode) <= 160 * 1024;
+  return a.halo_px <= 448 && bx3w_lds_bytes(a, mode) <= 160 * 1024;
 }
 
 int conv_bx3_init() {
   int rc = 0;
-#define RAISE(NTV, M) rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bx3_kernel<NTV, M>), \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-  RAISE(1, CONV_S1); RAISE(1, CONV_UP2); RAISE(1, CONV_T2);
-  RAISE(2, CONV_S1); RAISE(2, CONV_UP2); RAISE(2, CONV_T2);
-#undef RAISE
+#define RAISEW(NTV, M, P) rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bx3w_kernel<NTV, M, P>), \
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+  RAISEW(1, CONV_S1, false); RAISEW(1, CONV_UP2, false); RAISEW(1, CONV_T2, false);
+  RAISEW(2, CONV_S1, false); RAISEW(2, CONV_UP2, false); RAISEW(2, CONV_T2, false);
+  RAISEW(2, CONV_S1, true); RAISEW(2, CONV_UP2, true); RAISEW(2, CONV_T2, true);
+#undef RAISEW
   return rc;
 }
 
 void launch_conv_bx3(const ConvArgs& a, int mode, hipStream_t s) {
   const int nt = (a.Cout % 64 == 0) ? 2 : 1;
-  dim3 grid(geom_num_tiles(a.g, a.B), a.Cout / (32 * nt), mode == CONV_T2 ? 4 : 1);
-  const size_t lds = bx3_lds_bytes(a, mode);
-#define LAUNCH3(NTV, M) hipLaunchKernelGGL((conv_mfma_bx3_kernel<NTV, M>), grid, dim3(256), lds, s, a)
-  if (nt == 2) {
-    if (mode == CONV_S1) LAUNCH3(2, CONV_S1);
-    else if (mode == CONV_UP2) LAUNCH3(2, CONV_UP2);
-    else LAUNCH3(2, CONV_T2);
-  } else {
-    if (mode == CONV_S1) LAUNCH3(1, CONV_S1);
-    else if (mode == CONV_UP2) LAUNCH3(1, CONV_UP2);
-    else LAUNCH3(1, CONV_T2);
+  {
+    const int tiles = geom_num_tiles(a.g, a.B);
+    const bool pn = bx3_pairn(a);  // nt == 2 and Cout % 128 == 0
+    dim3 grid(pn ? tiles : (tiles + 1) / 2, pn ? a.Cout / 128 : a.Cout / (32 * nt), mode == CONV_T2 ? 4 : 1);
+    const size_t lds = bx3w_lds_bytes(a, mode);
+#define LAUNCHW(NTV, M, P) hipLaunchKernelGGL((conv_mfma_bx3w_kernel<NTV, M, P>), grid, dim3(512), lds, s, a, tiles)
+    if (pn) {
+      if (mode == CONV_S1) LAUNCHW(2, CONV_S1, true);
+      else if (mode == CONV_UP2) LAUNCHW(2, CONV_UP2, true);
+      else LAUNCHW(2, CONV_T2, true);
+    } else if (nt == 2) {
+      if (mode == CONV_S1) LAUNCHW(2, CONV_S1, false);
+      else if (mode == CONV_UP2) LAUNCHW(2, CONV_UP2, false);
+      else LAUNCHW(2, CONV_T2, false);
+    } else {
+      if (mode == CONV_S1) LAUNCHW(1, CONV_S1, false);
+      else if (mode == CONV_UP2) LAUNCHW(1, CONV_UP2, false);
+      else LAUNCHW(1, CONV_T2, false);
+    }
+#undef LAUNCHW
   }
-#undef LAUNCH3
 }
 
 }  // namespace rgfm

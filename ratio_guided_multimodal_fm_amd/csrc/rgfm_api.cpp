@@ -380,7 +380,7 @@ int check_desc(const rgfm_unet_desc* d) {
 
 void pack_one(const rgfm_unet* h, const ConvW& w, hipStream_t s) {
   launch_pack_conv(h->params + w.w_raw, h->packed + w.w_pk, w.cout, w.cin, w.taps, nt32_of(w.cout), s);
-  launch_pack_conv_bx3(h->params + w.w_raw, h->packed3 + w.w_bx3, w.cout, w.cin, w.taps, nt32_of(w.cout), s);
+  launch_pack_conv_bx3(h->params + w.w_raw, h->packed3 + w.w_bx3, w.cout, w.cin, w.taps, s);
   if (w.has_wino) launch_wino_pack(h->params + w.w_raw, h->wino + w.w_wino, w.cout, w.cin, s);
 }
 
@@ -1406,10 +1406,10 @@ extern "C" int rgfm_fmnet_create(const rgfm_fmnet_desc* desc, const float* param
   if (hipMalloc(&h->packed3, (h->n_packed3 + 8) * sizeof(unsigned short)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(packed3)");
   if (hipMemcpyAsync(h->params, params_dev, n_floats * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
     return bail(RGFM_EHIP, "hipMemcpyAsync(params)");
-  for (const ConvW& w : h->ec) launch_pack_conv_bx3(h->params + w.w_raw, h->packed3 + w.w_bx3, w.cout, w.cin, 9, nt32_of(w.cout), s);
-  launch_pack_conv_bx3(h->params + h->c3.w_raw, h->packed3 + h->c3.w_bx3, 32, 64, 9, 1, s);
-  launch_pack_deconv_bx3(h->params + h->d1.w_raw, h->packed3 + h->d1.w_bx3, 256, 128, nt32_of(128), s);
-  launch_pack_deconv_bx3(h->params + h->d2.w_raw, h->packed3 + h->d2.w_bx3, 128, 64, nt32_of(64), s);
+  for (const ConvW& w : h->ec) launch_pack_conv_bx3(h->params + w.w_raw, h->packed3 + w.w_bx3, w.cout, w.cin, 9, s);
+  launch_pack_conv_bx3(h->params + h->c3.w_raw, h->packed3 + h->c3.w_bx3, 32, 64, 9, s);
+  launch_pack_deconv_bx3(h->params + h->d1.w_raw, h->packed3 + h->d1.w_bx3, 256, 128, s);
+  launch_pack_deconv_bx3(h->params + h->d2.w_raw, h->packed3 + h->d2.w_bx3, 128, 64, s);
   for (const ConvW& w : h->ec) launch_pack_conv(h->params + w.w_raw, h->packed + w.w_pk, w.cout, w.cin, 9, nt32_of(w.cout), s);
   launch_pack_conv(h->params + h->c3.w_raw, h->packed + h->c3.w_pk, 32, 64, 9, 1, s);
   launch_pack_deconv(h->params + h->d1.w_raw, h->packed + h->d1.w_pk, 256, 128, nt32_of(128), s);

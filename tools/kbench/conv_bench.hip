@@ -1,0 +1,127 @@
+// Single-layer benchmark of the conv kernels (development tool; not part of the library).
+//   conv_bench <S> <Cin> <Cout> [mode 0|2] [res 0|1|2] [B] [which: bx3|f32]
+// Builds one ConvArgs with random NHWC input / packed weights, launches it 20x, prints us and
+// fp32-equivalent TFLOP/s; with -DRGFM_BX3_PROF also the per-phase cycle counts of the bx3w kernel.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_bx3.hip"
+#include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma.hip"
+
+using namespace rgfm;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+static float* dev_rand(size_t n, float scale, unsigned seed) {
+  std::vector<float> h(n);
+  unsigned s = seed * 2654435761u + 12345u;
+  for (size_t i = 0; i < n; ++i) {
+    s = s * 1664525u + 1013904223u;
+    h[i] = scale * ((float)(s >> 8) / 8388608.0f - 1.0f);
+  }
+  float* d;
+  hipMalloc(&d, n * sizeof(float));
+  hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice);
+  return d;
+}
+
+__global__ void pack_plain(const float* w, float* out, int Cout, int Cin, int taps, int nb) {
+  const size_t total = (size_t)Cout * Cin * taps;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int kk = i % 16;
+    size_t r = i / 16;
+    const int n = r % nb;
+    r /= nb;
+    const int tap = r % taps;
+    r /= taps;
+    const int nch = Cin / 16;
+    const int ch = r % nch;
+    const int blk = r / nch;
+    out[i] = w[((size_t)(blk * nb + n) * Cin + ch * 16 + kk) * taps + tap];
+  }
+}
+
+int main(int argc, char** argv) {
+  const int S = argc > 1 ? atoi(argv[1]) : 32, Cin = argc > 2 ? atoi(argv[2]) : 64, Cout = argc > 3 ? atoi(argv[3]) : 64;
+  const int mode = argc > 4 ? atoi(argv[4]) : 0, res = argc > 5 ? atoi(argv[5]) : 0, B = argc > 6 ? atoi(argv[6]) : 512;
+  const bool f32 = argc > 7 && strcmp(argv[7], "f32") == 0;
+  const int Sin = mode == CONV_UP2 ? S / 2 : S;
+  const int nt = Cout % 64 == 0 ? 2 : 1;
+  CK(hipSetDevice(0));
+  conv_mfma_init();
+  conv_bx3_init();
+  ConvArgs a{};
+  a.in0 = dev_rand((size_t)B * Sin * Sin * Cin, 1.f, 1);
+  a.C0 = Cin, a.Hin = a.Win = Sin;
+  a.ab = dev_rand((size_t)B * Cin * 2, 1.f, 2);
+  float* w = dev_rand((size_t)Cout * Cin * 9, 0.05f, 3);
+  float* wp;
+  hipMalloc(&wp, (size_t)Cout * Cin * 9 * 4);
+  pack_plain<<<256, 256>>>(w, wp, Cout, Cin, 9, 32 * nt);
+  void* w3;
+  hipMalloc(&w3, (size_t)Cout * Cin * 9 * 6);
+  launch_pack_conv_bx3(w, w3, Cout, Cin, 9, 0);
+  a.wpk = wp, a.wpk3 = w3;
+  a.bias = dev_rand(Cout, 0.1f, 4);
+  a.temb = dev_rand(Cout, 0.1f, 5), a.temb_stride = Cout;
+  a.res_mode = res;
+  int skipk = 0;
+  if (res == 1) a.res0 = dev_rand((size_t)B * S * S * Cout, 1.f, 6), a.R0 = Cout;
+  if (res == 2) {
+    const int R = Cin;  // 1x1 skip from an R-channel source at output resolution
+    a.res0 = dev_rand((size_t)B * S * S * R, 1.f, 6), a.R0 = R;
+    float* ws = dev_rand((size_t)Cout * R, 0.05f, 7);
+    float* wsp;
+    hipMalloc(&wsp, (size_t)Cout * R * 4);
+    pack_plain<<<64, 256>>>(ws, wsp, Cout, R, 1, 32 * nt);
+    void* ws3;
+    hipMalloc(&ws3, (size_t)Cout * R * 6);
+    launch_pack_conv_bx3(ws, ws3, Cout, R, 1, 0);
+    a.wskip = wsp, a.wskip3 = ws3, a.skip_bias = dev_rand(Cout, 0.1f, 8);
+    skipk = R;
+  }
+  float* out;
+  hipMalloc(&out, (size_t)B * S * S * Cout * 4);
+  a.out = out;
+  a.g = make_geom(S, S);
+  float* st;
+  hipMalloc(&st, (size_t)B * a.g.nparts * Cout * 2 * 4);
+  a.stats_out = st;
+  a.B = B, a.Cout = Cout;
+  a.halo_px = a.g.spt * (a.g.th + 2) * (a.g.W + 2);
+  const double flops = 2.0 * B * S * S * (double)Cout * (9 * Cin + skipk);
+  auto launch = [&]() { if (f32) launch_conv_mfma(a, mode, 0); else launch_conv_bx3(a, mode, 0); };
+  launch();
+  CK(hipDeviceSynchronize());
+  CK(hipGetLastError());
+#ifdef RGFM_BX3_PROF
+  unsigned long long zero[8] = {0};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_bx3_prof), zero, sizeof(zero));
+#endif
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0), hipEventCreate(&e1);
+  const int reps = 20;
+  hipEventRecord(e0);
+  for (int i = 0; i < reps; ++i) launch();
+  hipEventRecord(e1);
+  CK(hipEventSynchronize(e1));
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double us = ms * 1e3 / reps;
+  printf("%s S=%d Cin=%d Cout=%d mode=%d res=%d B=%d: %8.1f us  %6.1f TFLOP/s (fp32-equivalent)\n", f32 ? "f32" : "bx3", S, Cin,
+         Cout, mode, res, B, us, flops / us / 1e6);
+#ifdef RGFM_BX3_PROF
+  unsigned long long p[8];
+  hipMemcpyFromSymbol(p, HIP_SYMBOL(g_bx3_prof), sizeof(p));
+  const double nb = (double)p[7];
+  const char* names[7] = {"prologue", "issue", "mfma", "commit-wait", "commit-A", "commit-B", "epilogue"};
+  double tot = 0;
+  for (int i = 0; i < 7; ++i) tot += (double)p[i];
+  for (int i = 0; i < 7; ++i) printf("  %-12s %10.0f clk/block  %5.1f%%\n", names[i], p[i] / nb, 100.0 * p[i] / tot);
+  printf("  total        %10.0f clk/block over %.0f block-launches\n", tot / nb, nb);
+#endif
+  return 0;
+}
