@@ -15,8 +15,13 @@ on noise that is already resident in HBM.  Synthetic parameters
 CPU-generator noise seeded 42 (the reference CLI's default seed).
 
 Rank 0 prints ONE JSON line with the driver's contract fields plus
-  roofline     : fp32-MFMA conv kernel class, hipEvent-timed on the launch stream
-                 inside the timed region (librgfm_hip's rgfm_profile_*)
+  roofline     : the conv kernel class, hipEvent-timed on the launch streams inside the
+                 timed region (librgfm_hip's rgfm_profile_*).  Default arithmetic (RGFM_CONV
+                 unset / bx3): fp32 operands split exactly into three bf16 planes, six
+                 bf16-MFMA products per fp32 product, fp32 accumulate -> peak = dense bf16
+                 peak / 6 in fp32-equivalent TFLOP/s.  RGFM_CONV=f32: v_mfma_f32_32x32x2_f32,
+                 peak 157.3.  At N=1 one extra (untimed-for-`value`) call in the other mode is
+                 reported as roofline.exact_fp32_mode.
   cpu_baseline : the CPU oracle (a C port of the reference algorithm, test
                  infrastructure) timed on this host's cores on a bounded sample.
 """
@@ -32,7 +37,9 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
+BX3_PRODUCTS = 6                # bf16 MFMA products per fp32 multiply-add in conv_mfma_bx3.hip
 
 
 def parse():
@@ -47,6 +54,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-timers", action="store_true",
                    help="skip the hipEvent kernel-class timers (use under rocprofv3)")
+    p.add_argument("--no-alt-mode", action="store_true",
+                   help="skip the extra call in exact-fp32-MFMA mode (reported beside the default mode)")
     return p.parse_args()
 
 
@@ -139,6 +148,24 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    conv_mode = os.environ.get("RGFM_CONV", "bx3")
+    alt = None
+    if rank == 0 and world == 1 and timers and conv_mode == "bx3" and not args.no_alt_mode:
+        # the same call once more with the exact-fp32 MFMA conv (the switch is read per launch)
+        os.environ["RGFM_CONV"] = "f32"
+        one_call(calls - 1)
+        fence()
+        _engine.profile(enable=True, reset=True)
+        ta = time.perf_counter()
+        one_call(calls - 1)
+        fence()
+        alt_elapsed = time.perf_counter() - ta
+        a_ms, _, a_n, a_fl = _engine.profile_read(0)
+        _engine.profile(enable=False)
+        os.environ["RGFM_CONV"] = conv_mode
+        ach_a = a_fl / (a_ms * 1e-3) / 1e12
+        alt = {"conv": "v_mfma_f32_32x32x2_f32 (RGFM_CONV=f32)", "value": B / alt_elapsed, "unit": "paired images/sec",
+               "achieved": ach_a, "peak": PEAK_FP32_MFMA_TFLOPS, "frac": ach_a / PEAK_FP32_MFMA_TFLOPS, "calls": 1}
 
     if rank == 0:
         assert out[0] is not None and out[0].shape[0] == B and torch.isfinite(out[0]).all()
@@ -154,7 +181,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32",  # fp32 tensors and accumulation end to end; see roofline.conv_arithmetic
             "data": "synthetic",
             "config": {
                 "workload": "MNIST32 (1x32x32) + SVHN (3x32x32) pair, mc_feng guidance "
@@ -174,10 +201,20 @@ def main():
             if os.path.exists(tpath) and args.batch_per_gpu == 512:
                 with open(tpath) as f:
                     traffic = json.load(f).get("per_launch_avg_bytes")
+            if conv_mode == "bx3":
+                peak = PEAK_BF16_MFMA_TFLOPS / BX3_PRODUCTS
+                kern = ("conv_mfma_bx3w_kernel (implicit-GEMM conv; fp32 operands as 3 exact bf16 planes, 6 bf16-MFMA "
+                        "products per fp32 product, fp32 accumulate; stride-2 convs on conv_mfma_kernel)")
+                basis = (f"fp32-equivalent: {PEAK_BF16_MFMA_TFLOPS:.0f} TFLOP/s dense bf16 MFMA / {BX3_PRODUCTS} products; "
+                         "achieved counts algorithmic conv FLOPs (2*MAC) once")
+            else:
+                peak = PEAK_FP32_MFMA_TFLOPS
+                kern = "conv_mfma*_kernel (fp32 MFMA implicit-GEMM conv, all shapes)"
+                basis = "v_mfma_f32_32x32x2_f32 dense peak"
             line["roofline"] = {
-                "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                "kernel": "conv_mfma*_kernel (fp32 MFMA implicit-GEMM conv, all shapes)",
+                "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                "frac": ach / peak, "traffic": traffic if conv_mode != "bx3" else None,
+                "kernel": kern, "peak_basis": basis, "conv_arithmetic": conv_mode,
                 "launches": int(conv_n), "avg_launch_us": 1e3 * conv_sum_ms / max(conv_n, 1),
                 "busy_ms": conv_ms, "sum_launch_ms": conv_sum_ms,
                 "timing": "hipEvents on the launch streams over the timed region; achieved = algorithmic FLOPs / "
@@ -185,6 +222,8 @@ def main():
                           "launches overlap; sum_launch_ms double-counts that time; RGFM_OVERLAP=0 serialises)",
                 "kernel_time_share": conv_ms * 1e-3 / elapsed,
             }
+            if alt is not None:
+                line["roofline"]["exact_fp32_mode"] = alt
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)

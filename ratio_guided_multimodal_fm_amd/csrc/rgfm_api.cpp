@@ -216,11 +216,13 @@ bool use_v3() {
   const char* e = getenv("RGFM_CONV");
   return e && strcmp(e, "v3") == 0;
 }
-// RGFM_CONV=bx3 routes supported convs through conv_mfma_bx3.hip (fp32 operands as three exact bf16
-// planes, six bf16-MFMA products, fp32 accumulate); RGFM_CONV=f32 forces v_mfma_f32_32x32x2_f32.
+// Conv arithmetic (read per launch).  Default: conv_mfma_bx3.hip -- fp32 operands as three exact bf16
+// planes, six bf16-MFMA products per fp32 product, fp32 accumulate (same error against float64 as
+// the fp32 MFMA, tests/test_gpu_parity.py::test_arithmetic_error_against_float64).
+// RGFM_CONV=f32 forces v_mfma_f32_32x32x2_f32 (conv_mfma.hip) everywhere.
 bool use_bx3() {
   const char* e = getenv("RGFM_CONV");
-  return e && strcmp(e, "bx3") == 0;
+  return !e || strcmp(e, "bx3") == 0;
 }
 int ensure_init() {
   if (!on_gfx950()) return fail(RGFM_ENODEVICE, "librgfm_hip needs a gfx950 (MI355X) device; none is current");

@@ -160,6 +160,27 @@ def gen_unet_layers():
         save(f"unet_layers_{tag}", **out)
 
 
+def gen_fp64():
+    """The reference nets evaluated in float64 (same weights and inputs, cast up): the yardstick for
+    the arithmetic error of the fp32-MFMA and the split-bf16 (bx3) conv paths."""
+    cases = [("unet28", RefUNet28, ours.FlowMatchingUNet, (), (1, 28, 28)),
+             ("mnist32", RefUNetMNIST, ours.FlowMatchingUNetMNIST, (32,), (1, 32, 32)),
+             ("svhn", RefUNetSVHN, ours.FlowMatchingUNetSVHN, (), (3, 32, 32)),
+             ("fm_original", RefFMOriginal, ours.FlowMatchingModel, (), (1, 28, 28))]
+    out = {}
+    for tag, rc, oc, args, shape in cases:
+        ref = build(rc, oc, SEED_W[tag], *args)
+        x = torch.randn(4, *shape, generator=torch.Generator().manual_seed(91))
+        t = torch.tensor([0.05, 0.37, 0.71, 0.99])
+        with torch.no_grad():
+            o32 = ref(x, t)
+            o64 = ref.double()(x.double(), t.double())
+        out[f"{tag}_f64"] = o64.numpy()
+        out[f"{tag}_ref32_err"] = np.array(float((o32.double() - o64).abs().max()))
+        out[f"{tag}_x_fp"] = n(x.reshape(-1)[:8])
+    save("fp64_eval", **out)
+
+
 # ---------------------------------------------------------------- ratio nets
 def gen_ratio():
     g = torch.Generator().manual_seed(78)
@@ -367,8 +388,8 @@ def gen_fm_original():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["embedding", "unet_layers", "ratio", "guidance", "samplers", "coherence", "fm_original", "coherence28"]
+    which = sys.argv[1:] or ["embedding", "unet_layers", "ratio", "guidance", "samplers", "coherence", "fm_original", "coherence28", "fp64"]
     for w in which:
         {"embedding": gen_embedding, "unet_layers": gen_unet_layers, "ratio": gen_ratio,
          "guidance": gen_guidance, "samplers": gen_samplers, "coherence": gen_coherence,
-         "fm_original": gen_fm_original, "coherence28": gen_coherence28}[w]()
+         "fm_original": gen_fm_original, "coherence28": gen_coherence28, "fp64": gen_fp64}[w]()

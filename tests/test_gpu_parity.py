@@ -330,11 +330,12 @@ def test_full_size_properties(dev):
     assert maxdiff(ya[rows].cpu().numpy(), oy) < TOL_SAMPLER
 
 
-@pytest.mark.parametrize("env", [{"RGFM_WINO": "1"}, {"RGFM_CONV": "v3"}, {"RGFM_CONV": "bx3"}])
+@pytest.mark.parametrize("env", [{"RGFM_CONV": "f32"}, {"RGFM_CONV": "f32", "RGFM_WINO": "1"}, {"RGFM_CONV": "v3"}])
 @pytest.mark.parametrize("tag,B", [("svhn", 5), ("mnist32", 3)])
 def test_experimental_conv_variants_keep_parity(dev, env, tag, B, monkeypatch):
-    """The opt-in conv variants (Winograd F(2x2,3x3): RGFM_WINO=1; persistent one-block-per-CU kernel:
-    RGFM_CONV=v3; both read per launch) must stay inside the same tolerance as the default path."""
+    """The alternative conv paths (exact-fp32 MFMA: RGFM_CONV=f32; with Winograd F(2x2,3x3): + RGFM_WINO=1;
+    persistent one-block-per-CU fp32 kernel: RGFM_CONV=v3; all read per launch) must stay inside the same
+    tolerance as the default split-bf16 path."""
     m = make_module(tag, dev)
     desc, blob = oracle_net(tag)
     x = torch.randn(B, *SHAPES[tag], generator=torch.Generator().manual_seed(5))
@@ -344,6 +345,29 @@ def test_experimental_conv_variants_keep_parity(dev, env, tag, B, monkeypatch):
         monkeypatch.setenv(k, v)
     out = m(x.to(dev), t.to(dev)).cpu().numpy()
     assert maxdiff(out, ro) < TOL_EVAL
+
+
+@pytest.mark.parametrize("tag", ["unet28", "mnist32", "svhn", "fm_original"])
+def test_arithmetic_error_against_float64(dev, tag, monkeypatch):
+    """Error budget of the two conv arithmetic modes against the reference evaluated in float64
+    (tests/golden/fp64_eval.npz): RGFM_CONV=f32 (v_mfma_f32_32x32x2_f32, exact fp32 products) and
+    RGFM_CONV=bx3 (operands as three exact bf16 planes, six bf16-MFMA products, fp32 accumulate).
+    Both must sit in the reference's own fp32-vs-fp64 error class (its own error is ~1.4e-6..2e-6)."""
+    g = golden("fp64_eval")
+    shape = (1, 28, 28) if tag in ("unet28", "fm_original") else SHAPES[tag]
+    x = torch.randn(4, *shape, generator=torch.Generator().manual_seed(91))
+    assert np.array_equal(x.reshape(-1)[:8].numpy(), g[f"{tag}_x_fp"])
+    t = torch.tensor([0.05, 0.37, 0.71, 0.99])
+    m = make_module(tag, dev)
+    ref_err = float(g[f"{tag}_ref32_err"])
+    errs = {}
+    for mode in ("f32", "bx3"):
+        monkeypatch.setenv("RGFM_CONV", mode)
+        out = m(x.to(dev), t.to(dev)).cpu().numpy().astype(np.float64)
+        errs[mode] = float(np.abs(out - g[f"{tag}_f64"]).max())
+    print(f"{tag}: max|err| vs float64  reference-fp32 {ref_err:.2e}  f32-MFMA {errs['f32']:.2e}  bx3 {errs['bx3']:.2e}")
+    assert errs["f32"] < 5e-6 and errs["bx3"] < 5e-6
+    assert errs["bx3"] < 2.0 * max(errs["f32"], ref_err)
 
 
 def test_rccl_collectives_single_rank(dev):
