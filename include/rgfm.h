@@ -18,7 +18,12 @@
  *   - return value: 0 on success, a negative RGFM_E* code otherwise; nothing is
  *     thrown across the ABI; rgfm_last_error() returns text for the calling
  *     thread's last failure;
- *   - one host thread per handle; distinct handles are independent.
+ *   - one host thread per handle; distinct handles are independent;
+ *   - arithmetic: fp32 tensors, fp32 accumulation.  The 3x3 / transposed convolutions form
+ *     each fp32 product from an exact three-way bf16 split of both operands on the bf16
+ *     matrix cores (six products, fp32 accumulate; error against float64 equal to the
+ *     fp32 matrix-core path).  Environment variable RGFM_CONV=f32
+ *     (read per launch) selects v_mfma_f32_32x32x2_f32 for every convolution instead.
  */
 #ifndef RGFM_H_
 #define RGFM_H_

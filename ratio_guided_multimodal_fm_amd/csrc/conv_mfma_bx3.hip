@@ -44,7 +44,7 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& ph, unsigned&
 // 8 records, which keeps ds_read_b128 conflict-free for 16 consecutive records.
 // ------------------------------------------------------------------------------------
 #ifdef RGFM_BX3_PROF
-__device__ unsigned long long g_bx3_prof[8];  // prologue, issue, mfma, commit-wait, commit-A, commit-B, epilogue, blocks
+__device__ unsigned long long g_bx3_prof[10];  // prologue, issue, mfma, commit-wait, commit-A, commit-B, epilogue, blocks, [8] shader clk, [9] 100 MHz ticks
 #define PROF_T(var) const long long var = clock64()
 #define PROF_ADD(slot, t0, t1) prof_acc[slot] += (t1) - (t0)
 #else
@@ -67,6 +67,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
   extern __shared__ __attribute__((aligned(16))) char smem3[];
 #ifdef RGFM_BX3_PROF
   long long prof_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  const long long wall0 = wall_clock64();
 #endif
   PROF_T(tp0);
   char* sA = smem3;
@@ -367,13 +368,6 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
   int lane_e = lane;
   asm volatile("" : "+v"(lane_e));
   const int l31 = lane_e & 31, h = lane_e >> 5;
-  float eps_[NT], eph_[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int c = n0 + nt * 32 + l31;
-    eps_[nt] = a.ep_scale ? a.ep_scale[c] : 1.f;
-    eph_[nt] = a.ep_scale ? a.ep_shift[c] : 0.f;
-  }
   unsigned vmask[2] = {0u, 0u};
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
@@ -392,10 +386,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int c = n0 + nt * 32 + l31;
-        float v = acc[mt][nt][r];
-        if (a.ep_scale) v = silu_f(v * eps_[nt] + eph_[nt]);
-        acc[mt][nt][r] = v;
-        if (valid) a.out[pix * a.Cout + c] = v;
+        if (valid) a.out[pix * a.Cout + c] = acc[mt][nt][r];
       }
     }
   if (a.stats_out) {
@@ -444,6 +435,8 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
   if (threadIdx.x == 0) {
     for (int i = 0; i < 7; ++i) atomicAdd(&g_bx3_prof[i], (unsigned long long)prof_acc[i]);
     atomicAdd(&g_bx3_prof[7], 1ull);
+    atomicAdd(&g_bx3_prof[8], (unsigned long long)(te1 - tp0));
+    atomicAdd(&g_bx3_prof[9], (unsigned long long)(wall_clock64() - wall0));
   }
 #endif
 }
@@ -527,7 +520,7 @@ static size_t bx3w_lds_bytes(const ConvArgs& a, int mode) {
   return (size_t)((pn ? 1 : 2) * a.halo_px + ntaps * 32 * nt * (pn ? 2 : 1)) * RW + 2 * 128 * sizeof(float);
 }
 bool conv_bx3_supported(const ConvArgs& a, int mode) {
-  if (mode == CONV_S2 || !a.wpk3) return false;
+  if (mode == CONV_S2 || !a.wpk3 || a.ep_scale) return false;  // (the BatchNorm+SiLU epilogue of the ratio nets stays on conv_mfma.hip)
   if (a.res_mode == 2 && !a.wskip3) return false;
   return a.halo_px <= 448 && bx3w_lds_bytes(a, mode) <= 160 * 1024;
 }

@@ -98,7 +98,7 @@ int main(int argc, char** argv) {
   CK(hipDeviceSynchronize());
   CK(hipGetLastError());
 #ifdef RGFM_BX3_PROF
-  unsigned long long zero[8] = {0};
+  unsigned long long zero[10] = {0};
   hipMemcpyToSymbol(HIP_SYMBOL(g_bx3_prof), zero, sizeof(zero));
 #endif
   hipEvent_t e0, e1;
@@ -114,14 +114,15 @@ int main(int argc, char** argv) {
   printf("%s S=%d Cin=%d Cout=%d mode=%d res=%d B=%d: %8.1f us  %6.1f TFLOP/s (fp32-equivalent)\n", f32 ? "f32" : "bx3", S, Cin,
          Cout, mode, res, B, us, flops / us / 1e6);
 #ifdef RGFM_BX3_PROF
-  unsigned long long p[8];
+  unsigned long long p[10];
   hipMemcpyFromSymbol(p, HIP_SYMBOL(g_bx3_prof), sizeof(p));
   const double nb = (double)p[7];
   const char* names[7] = {"prologue", "issue", "mfma", "commit-wait", "commit-A", "commit-B", "epilogue"};
   double tot = 0;
   for (int i = 0; i < 7; ++i) tot += (double)p[i];
   for (int i = 0; i < 7; ++i) printf("  %-12s %10.0f clk/block  %5.1f%%\n", names[i], p[i] / nb, 100.0 * p[i] / tot);
-  printf("  total        %10.0f clk/block over %.0f block-launches\n", tot / nb, nb);
+  printf("  total        %10.0f clk/block over %.0f block-launches; shader clock during the blocks: %.0f MHz\n", tot / nb, nb,
+         100.0 * (double)p[8] / (double)p[9]);
 #endif
   return 0;
 }
