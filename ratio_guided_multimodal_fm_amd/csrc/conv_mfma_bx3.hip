@@ -80,6 +80,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
   const TileGeom g = a.g;
   const int W = g.W, H = g.H, HW = g.HW;
 
+  // tile origins of the block's one or two pixel tiles (block-uniform: scalar registers)
   auto tile_origin = [&](int tile, int& b0, int& row0) {
     if (tile >= num_tiles) {
       b0 = a.B, row0 = 0;  // idle half of the last block: every sample index is out of range
@@ -91,10 +92,18 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
       row0 = 0;
     }
   };
+  int tb0_[2], trow0_[2];
+  tile_origin(PAIRN ? (int)blockIdx.x : (int)blockIdx.x * 2, tb0_[0], trow0_[0]);
+  tile_origin(PAIRN ? (int)blockIdx.x : (int)blockIdx.x * 2 + 1, tb0_[1], trow0_[1]);
+  const int ga_w = PAIRN ? 0 : grp;
   const int my_tile = PAIRN ? (int)blockIdx.x : (int)blockIdx.x * 2 + grp;
   const int my_cb = PAIRN ? (int)blockIdx.y * 2 + grp : (int)blockIdx.y;
-  int b0, row0;
-  tile_origin(my_tile, b0, row0);
+  const int b0 = ga_w ? tb0_[1] : tb0_[0], row0 = ga_w ? trow0_[1] : trow0_[0];
+  // exact n / d for 0 <= n < 2048 as (n * m) >> 16 with m = ceil(65536 / d): full-rate 24-bit multiplies
+  // instead of the emulated 32-bit division (n (d - 1) < 65536 holds: n <= 1791, d <= 34)
+  const unsigned mW = (65536u + (unsigned)g.W - 1u) / (unsigned)g.W;
+  const unsigned mWR = (65536u + (unsigned)g.W + 1u) / (unsigned)(g.W + 2);
+  const unsigned mPER = (65536u + (unsigned)((g.th + 2) * (g.W + 2)) - 1u) / (unsigned)((g.th + 2) * (g.W + 2));
   const int n0 = my_cb * NBLK;
   const int pc = (MODE == CONV_T2) ? (int)blockIdx.z : 0, py = pc >> 1, px = pc & 1;
   const int HR = g.th + 2, WR = W + 2;
@@ -114,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
       s = seg;
       q = (p & 63) < HW ? (p & 63) : HW - 1;
     }
-    const int r = q / W, x = q - r * W;
+    const int r = (int)(__umul24((unsigned)q, mW) >> 16), x = q - r * W;
     arec[mt] = (PAIRN ? 0 : grp) * a.halo_px + (s * HR + r) * WR + x;
   }
   int bbase[NT];
@@ -146,9 +155,10 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
           const int pl = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hp_;
           const int p = 64 * seg + pl;
           const bool valid = (g.spt == 1) ? (sample_ok && p < nvalid) : (sample_ok && pl < HW);
-          const size_t pix = valid ? pix0 + ((g.spt == 1) ? p : pl) : 0;
+          const unsigned pix = valid ? (unsigned)pix0 + (unsigned)((g.spt == 1) ? p : pl) : 0u;
+          const float* rp = a.res0 + (size_t)(__umul24(pix, (unsigned)a.Cout) + (unsigned)(n0 + l31p));
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] = a.res0[pix * a.Cout + n0 + nt * 32 + l31p];
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] = rp[nt * 32];
         }
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
@@ -180,12 +190,12 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
       if (it < NA * nA) {
         const int ga = (NA == 2 && it >= nA) ? 1 : 0;
         const int ita = it - ga * nA;
-        int tb0, trow0;
-        tile_origin(PAIRN ? (int)blockIdx.x : (int)blockIdx.x * 2 + ga, tb0, trow0);
+        const int tb0 = ga ? tb0_[1] : tb0_[0], trow0 = ga ? trow0_[1] : trow0_[0];
         const int hp = ita >> 2;
-        const int s = hp / per;
+        // hp < 448; per = HR * WR >= 81 when spt == 4 (hp (per - 1) < 65536 needs hp <= 448: per <= 146 there)
+        const int s = (g.spt == 1) ? 0 : (int)(__umul24((unsigned)hp, mPER) >> 16);
         const int rem = hp - s * per;
-        const int hy = rem / WR, hx = rem - hy * WR;
+        const int hy = (int)(__umul24((unsigned)rem, mWR) >> 16), hx = rem - hy * WR;
         const int b = tb0 + s;
         int y, x;
         bool ok;
@@ -199,10 +209,10 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
         }
         ok = ok && (b < a.B);
         const int rec = ga * a.halo_px + hp;
-        adst[j] = rec * RW + swz(rec, q4 >> 1) + (q4 & 1) * 8;
+        adst[j] = (int)__umul24((unsigned)rec, RW) + swz(rec, q4 >> 1) + (q4 & 1) * 8;
         inmask |= 1u << j;
         if (ok) {
-          poff[j] = (b * a.Hin + y) * a.Win + x;
+          poff[j] = (int)__umul24(__umul24((unsigned)b, (unsigned)a.Hin) + (unsigned)y, (unsigned)a.Win) + x;  // < 2^24 pixels
           okmask |= 1u << j;
           smask |= (unsigned)(ga * 4 + s) << (3 * j);
         }
@@ -213,9 +223,8 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
   int ab_b = -1;
   if (tid < NA * g.spt * 8) {
     const int slot = tid >> 3;
-    const int ga = slot / g.spt, s = slot - ga * g.spt;
-    int tb0, trow0;
-    tile_origin(PAIRN ? (int)blockIdx.x : (int)blockIdx.x * 2 + ga, tb0, trow0);
+    const int ga = (g.spt == 1) ? slot : (slot >> 2), s = (g.spt == 1) ? 0 : (slot & 3);
+    const int tb0 = ga ? tb0_[1] : tb0_[0];
     if (tb0 + s < a.B) ab_b = tb0 + s;
   }
   const int ab_slot = (NA == 2 && g.spt == 1) ? (tid >> 3) * 4 : (tid >> 3);  // table index ga * 4 + s
@@ -251,7 +260,8 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
     for (int j = 0; j < MAXIT; ++j) ra[j] = *(const bx_gf32x4*)(src + (((size_t)poff[j] * cs + cc) & 0x3FF) + q4 * 4);  // experiment
 #else
 #pragma unroll
-    for (int j = 0; j < MAXIT; ++j) ra[j] = *(const bx_gf32x4*)(src + (size_t)poff[j] * cs + cc + q4 * 4);
+    for (int j = 0; j < MAXIT; ++j)
+      ra[j] = *(const bx_gf32x4*)(src + (size_t)(__umul24((unsigned)poff[j], (unsigned)cs) + (unsigned)(cc + q4 * 4)));
 #endif
     // packed weights: the chunk's LDS image ([tap][NG groups][NBLK channels] records of 96 B, halves
     // pre-swapped) is contiguous in global memory (launch_pack_conv_bx3 with nb = NBLK * NG)
@@ -377,16 +387,16 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
       const int p = 64 * seg + pl;
       const bool valid = (g.spt == 1) ? (sample_ok && p < nvalid) : (sample_ok && pl < HW);
       if (valid) vmask[mt] |= 1u << r;
-      size_t pix = pix0 + ((g.spt == 1) ? p : pl);
+      unsigned pix = (unsigned)pix0 + (unsigned)((g.spt == 1) ? p : pl);
       if (MODE == CONV_T2) {
         const int pp = (g.spt == 1) ? row0 * W + p : pl;
-        const int rr = pp / W, xx = pp - rr * W;
-        pix = ((size_t)bw * (2 * H) + 2 * rr + py) * (2 * W) + 2 * xx + px;
+        const int rr = (int)(__umul24((unsigned)pp, mW) >> 16), xx = pp - rr * W;
+        pix = (unsigned)((bw * (2 * H) + 2 * rr + py) * (2 * W) + 2 * xx + px);
       }
+      float* op = a.out + (size_t)(__umul24(pix, (unsigned)a.Cout) + (unsigned)(n0 + l31));
+      if (valid) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int c = n0 + nt * 32 + l31;
-        if (valid) a.out[pix * a.Cout + c] = acc[mt][nt][r];
+        for (int nt = 0; nt < NT; ++nt) op[nt * 32] = acc[mt][nt][r];
       }
     }
   if (a.stats_out) {
@@ -522,6 +532,10 @@ static size_t bx3w_lds_bytes(const ConvArgs& a, int mode) {
 bool conv_bx3_supported(const ConvArgs& a, int mode) {
   if (mode == CONV_S2 || !a.wpk3 || a.ep_scale) return false;  // (the BatchNorm+SiLU epilogue of the ratio nets stays on conv_mfma.hip)
   if (a.res_mode == 2 && !a.wskip3) return false;
+  // 24-bit pixel indices and 32-bit element offsets inside the kernel (B = 8192 rows of 32x32x256 still fit)
+  const size_t px_in = (size_t)a.B * a.Hin * a.Win, px_out = (size_t)a.B * a.g.HW * (mode == CONV_T2 ? 4 : 1);
+  const size_t cmax = (size_t)(a.C0 > a.C1 ? a.C0 : a.C1) > (size_t)a.Cout ? (size_t)(a.C0 > a.C1 ? a.C0 : a.C1) : (size_t)a.Cout;
+  if (px_in >= (1u << 24) || px_out >= (1u << 24) || (px_in > px_out ? px_in : px_out) * cmax >= (1ull << 32)) return false;
   return a.halo_px <= 448 && bx3w_lds_bytes(a, mode) <= 160 * 1024;
 }
 
