@@ -197,7 +197,7 @@ def main():
             # HBM bytes per conv launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
             # separate runs, gfx950 corrections applied by tools/pmc_traffic.py); bench.py cannot collect PMC itself
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic_bx3.json" if conv_mode == "bx3" else "r01_conv_traffic.json")
             if os.path.exists(tpath) and args.batch_per_gpu == 512:
                 with open(tpath) as f:
                     traffic = json.load(f).get("per_launch_avg_bytes")
@@ -213,7 +213,7 @@ def main():
                 basis = "v_mfma_f32_32x32x2_f32 dense peak"
             line["roofline"] = {
                 "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                "frac": ach / peak, "traffic": traffic if conv_mode != "bx3" else None,
+                "frac": ach / peak, "traffic": traffic,
                 "kernel": kern, "peak_basis": basis, "conv_arithmetic": conv_mode,
                 "launches": int(conv_n), "avg_launch_us": 1e3 * conv_sum_ms / max(conv_n, 1),
                 "busy_ms": conv_ms, "sum_launch_ms": conv_sum_ms,
