@@ -388,6 +388,38 @@ void pack_one(const rgfm_unet* h, const ConvW& w, hipStream_t s) {
 
 double conv_flops(int B, int HW, int cout, int kprod) { return 2.0 * B * HW * (double)cout * kprod; }
 
+// A conv that has been described but not launched yet: if the next thing the walk asks for is the
+// GroupNorm finalize of its output, the finalize is attached to it (ConvArgs::fin_*: the last wave per
+// sample computes the scale/shift) and no gn_finalize launch happens -- each such launch is a full
+// drain-and-refill bubble between two convs (measured: 18 % of the sampling call).
+struct PendingConv {
+  bool valid = false;
+  ConvArgs c{};
+  int mode = 0;
+  const float* wino = nullptr;
+  double flops = 0.0;
+};
+
+void flush_conv(PendingConv& p, hipStream_t s) {
+  if (!p.valid) return;
+  p.valid = false;
+  ProfScope ps(RGFM_KCLASS_CONV_MFMA, p.flops, s);
+  launch_conv(p.c, p.mode, p.wino, s);
+}
+
+// true when `p` can take the finalize of cat(its output, partner) itself
+bool try_fuse_finalize(PendingConv& p, const float* first_data, const float* stats1, int C1, const float* gamma,
+                       const float* beta, float* ab, unsigned* counter) {
+  static const bool off = getenv("RGFM_FUSE_FIN") && getenv("RGFM_FUSE_FIN")[0] == '0';  // A/B switch
+  if (off || !p.valid || !counter || p.c.out != first_data || !p.c.stats_out) return false;
+  if ((p.wino && use_wino()) || !use_bx3() || !conv_bx3_supported(p.c, p.mode)) return false;
+  if ((p.c.Cout + C1) % 8 != 0 || p.c.Cout + C1 < 32) return false;
+  if (p.c.g.nparts * (p.mode == CONV_T2 ? 4 : 1) > 16) return false;  // the finalizing wave holds <= 16 partials per channel
+  p.c.fin_ab = ab, p.c.fin_counter = counter, p.c.fin_expected = conv_bx3_fin_expected(p.c, p.mode);
+  p.c.fin_stats1 = stats1, p.c.fin_C1 = C1, p.c.fin_gamma = gamma, p.c.fin_beta = beta;
+  return true;
+}
+
 struct UNetRun {
   rgfm_unet* h;
   int B;
@@ -396,6 +428,8 @@ struct UNetRun {
   const float* temb_row;  // table row(s) for this evaluation
   int temb_per_row;
   bool dry;
+  unsigned* fin_counter = nullptr;  // [B] arrival counters (zero between launches) or null: separate gn_finalize
+  PendingConv pend{};
 
   Tensor new_tensor(int C, int S) {
     Tensor t;
@@ -412,6 +446,10 @@ struct UNetRun {
     const int C = a.C + (b ? b->C : 0);
     float* ab = ws->f((size_t)B * C * 2);
     if (dry) return ab;
+    const bool fused = try_fuse_finalize(pend, a.data, b ? b->stats : nullptr, b ? b->C : 0, h->params + gamma,
+                                         h->params + beta, ab, fin_counter);
+    flush_conv(pend, s);
+    if (fused) return ab;
     GnFinalizeArgs f{};
     f.stats0 = a.stats, f.stats1 = b ? b->stats : nullptr;
     f.C0 = a.C, f.C1 = b ? b->C : 0;
@@ -448,8 +486,9 @@ struct UNetRun {
     c.g = make_geom(So, So);
     c.halo_px = mode == CONV_S2 ? c.g.spt * (2 * c.g.th + 1) * (2 * c.g.W + 1) : c.g.spt * (c.g.th + 2) * (c.g.W + 2);
     const int kprod = 9 * w.cin + (res_mode == 2 ? sk->cin : 0);
-    ProfScope p(RGFM_KCLASS_CONV_MFMA, conv_flops(B, So * So, w.cout, kprod), s);
-    launch_conv(c, mode, w.has_wino ? h->wino + w.w_wino : nullptr, s);
+    flush_conv(pend, s);
+    pend.valid = true, pend.c = c, pend.mode = mode, pend.wino = w.has_wino ? h->wino + w.w_wino : nullptr;
+    pend.flops = conv_flops(B, So * So, w.cout, kprod);
     return o;
   }
   // ResBlock.forward (unet_flexible.py:71-85)
@@ -507,6 +546,7 @@ struct UNetRun {
     }
     float* ab = finalize(cur, nullptr, h->onw, h->onb);
     if (!dry) {
+      flush_conv(pend, s);
       ConvOutArgs co{};
       co.in = cur.data, co.ab = ab, co.w = h->params + h->ocw, co.bias = h->params + h->ocb;
       co.v_out = v_out, co.x_state = x_state, co.dt = dt, co.B = B, co.Cin = cur.C;
@@ -519,6 +559,8 @@ struct UNetRun {
     return RGFM_OK;
   }
 };
+
+size_t counter_bytes(int B) { return (((size_t)B * sizeof(unsigned)) + 255) & ~(size_t)255; }
 
 size_t unet_eval_bytes(rgfm_unet* h, int B) {
   Bump b;
@@ -624,7 +666,7 @@ static size_t table_bytes(const rgfm_unet* h, int rows) {
 
 extern "C" int rgfm_unet_workspace_bytes(const rgfm_unet* h, int batch, size_t* bytes) {
   if (!h || !bytes || batch < 1) return fail(RGFM_EINVAL, "bad argument");
-  *bytes = unet_eval_bytes(const_cast<rgfm_unet*>(h), batch) + table_bytes(h, batch);
+  *bytes = unet_eval_bytes(const_cast<rgfm_unet*>(h), batch) + table_bytes(h, batch) + counter_bytes(batch);
   return RGFM_OK;
 }
 
@@ -639,8 +681,11 @@ extern "C" int rgfm_unet_forward(rgfm_unet* h, const float* x, const float* t_de
   rgfm_unet_workspace_bytes(h, batch, &need);
   if (need > ws_bytes) return fail(RGFM_ENOMEM, "workspace too small: %zu < %zu", ws_bytes, need);
   float* table = b.f((size_t)t_count * h->temb_total);
+  unsigned* cnt = reinterpret_cast<unsigned*>(b.f(batch));
+  HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)batch * sizeof(unsigned), s));
   launch_time_table(h, t_dev, 1, 0, t_count, table, s);
   UNetRun r{h, batch, &b, s, table, t_count == batch ? 1 : 0, false};
+  r.fin_counter = cnt;
   int rc = r.run(x, v_out, nullptr, 0.f);
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
@@ -722,7 +767,7 @@ extern "C" int rgfm_unet_read_activation(rgfm_unet* h, int index, int batch, con
 extern "C" int rgfm_sample_single_workspace_bytes(const rgfm_unet* h, int batch, size_t* bytes) {
   if (!h || !bytes || batch < 1) return fail(RGFM_EINVAL, "bad argument");
   // the time table is sized for up to 4096 steps per call
-  *bytes = unet_eval_bytes(const_cast<rgfm_unet*>(h), batch) + table_bytes(h, 4096);
+  *bytes = unet_eval_bytes(const_cast<rgfm_unet*>(h), batch) + table_bytes(h, 4096) + counter_bytes(batch);
   return RGFM_OK;
 }
 
@@ -741,12 +786,15 @@ extern "C" int rgfm_sample_single(rgfm_unet* h, float* x_inout, int batch, int n
   Bump b;
   b.base = (char*)ws, b.cap = ws_bytes, b.dry = false;
   float* table = b.f((size_t)4096 * h->temb_total);
+  unsigned* cnt = reinterpret_cast<unsigned*>(b.f(batch));
+  HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)batch * sizeof(unsigned), s));
   launch_time_table(h, nullptr, num_steps, step_begin, ns, table, s);
   const size_t mark = b.off;
   const float dt = (float)(1.0 / (double)num_steps);
   for (int i = 0; i < ns; ++i) {
     b.off = mark;
     UNetRun r{h, batch, &b, s, table + (size_t)i * h->temb_total, 0, false};
+    r.fin_counter = cnt;
     int rc = r.run(x_inout, nullptr, x_inout, dt);
     if (rc) return rc;
   }
@@ -861,7 +909,7 @@ extern "C" int rgfm_sample_pair_workspace_bytes(const rgfm_unet* hx, const rgfm_
   const size_t ey = unet_eval_bytes(const_cast<rgfm_unet*>(hy), batch);
   const size_t dx = (size_t)hx->d.in_channels * hx->d.img_size * hx->d.img_size;
   const size_t dy = (size_t)hy->d.in_channels * hy->d.img_size * hy->d.img_size;
-  size_t total = table_bytes(hx, 4096) + table_bytes(hy, 4096) + ex + ey;  // the two nets run concurrently
+  size_t total = table_bytes(hx, 4096) + table_bytes(hy, 4096) + ex + ey + 2 * counter_bytes(batch);  // the two nets run concurrently
   total += ((batch * dx * 4 + 255) & ~(size_t)255) + ((batch * dy * 4 + 255) & ~(size_t)255);
   total += (((size_t)batch * (n_mc > 0 ? n_mc : 1) * 4) + 255) & ~(size_t)255;
   *bytes = total;
@@ -892,6 +940,10 @@ extern "C" int rgfm_sample_pair(rgfm_unet* hx, rgfm_unet* hy, float* x_inout, fl
   float* vx = b.f((size_t)batch * dx);
   float* vy = b.f((size_t)batch * dy);
   float* logp = b.f((size_t)batch * (n_mc > 0 ? n_mc : 1));
+  unsigned* cnt_x = reinterpret_cast<unsigned*>(b.f(batch));
+  unsigned* cnt_y = reinterpret_cast<unsigned*>(b.f(batch));
+  HIP_TRY(hipMemsetAsync(cnt_x, 0, (size_t)batch * sizeof(unsigned), s));
+  HIP_TRY(hipMemsetAsync(cnt_y, 0, (size_t)batch * sizeof(unsigned), s));
   launch_time_table(hx, nullptr, num_steps, step_begin, ns, tx, s);
   launch_time_table(hy, nullptr, num_steps, step_begin, ns, ty, s);
   const size_t mark_x = b.off;
@@ -899,11 +951,13 @@ extern "C" int rgfm_sample_pair(rgfm_unet* hx, rgfm_unet* hy, float* x_inout, fl
   auto eval_x = [&](int i, hipStream_t st, float* v_out, float* x_state, float dt) {
     b.off = mark_x;
     UNetRun r{hx, batch, &b, st, tx + (size_t)i * hx->temb_total, 0, false};
+    r.fin_counter = cnt_x;
     return r.run(x_inout, v_out, x_state, dt);
   };
   auto eval_y = [&](int i, hipStream_t st, float* v_out, float* y_state, float dt) {
     b.off = mark_y;
     UNetRun r{hy, batch, &b, st, ty + (size_t)i * hy->temb_total, 0, false};
+    r.fin_counter = cnt_y;
     return r.run(y_inout, v_out, y_state, dt);
   };
   return pair_loop(eval_x, eval_y, x_inout, y_inout, mc_x1, mc_y1, mc_ratios, n_mc, batch, num_steps, gamma,
@@ -1271,6 +1325,8 @@ struct FmRun {
   bool dry;
   const float* t_dev;  // explicit times (t_count 1 or B) or null: t of sampler step `step`
   int t_count, num_steps, step;
+  unsigned* fin_counter = nullptr;  // see UNetRun
+  PendingConv pend{};
 
   struct Map {  // NHWC activation + GroupNorm partials; rep 4 = written by a CONV_T2 launch over an (S/2)^2 raster
     float* data = nullptr;
@@ -1288,6 +1344,9 @@ struct FmRun {
   float* finalize(const Map& a, size_t gamma, size_t beta) {
     float* ab = ws->f((size_t)B * a.C * 2);
     if (dry) return ab;
+    const bool fused = try_fuse_finalize(pend, a.data, nullptr, 0, h->params + gamma, h->params + beta, ab, fin_counter);
+    flush_conv(pend, s);
+    if (fused) return ab;
     GnFinalizeArgs f{};
     f.stats0 = a.stats, f.C0 = a.C, f.groups = 8;
     f.gamma = h->params + gamma, f.beta = h->params + beta;
@@ -1310,8 +1369,8 @@ struct FmRun {
     c.g = make_geom(sg, sg);
     c.halo_px = mode == CONV_S2 ? c.g.spt * (2 * c.g.th + 1) * (2 * c.g.W + 1) : c.g.spt * (c.g.th + 2) * (c.g.W + 2);
     const double fl = mode == CONV_T2 ? conv_flops(B, 4 * sg * sg, w.cout, 4 * w.cin) : conv_flops(B, So * So, w.cout, 9 * w.cin);
-    ProfScope p(RGFM_KCLASS_CONV_MFMA, fl, s);
-    launch_conv(c, mode, nullptr, s);
+    flush_conv(pend, s);
+    pend.valid = true, pend.c = c, pend.mode = mode, pend.wino = nullptr, pend.flops = fl;
     return o;
   }
 
@@ -1337,6 +1396,7 @@ struct FmRun {
     float* part = ws->f((size_t)FM_FC_SPLITS * B * F);
     float* d0 = ws->f((size_t)B * FM_P * FM_CF);
     if (!dry) {
+      flush_conv(pend, s);
       ProfScope p(RGFM_KCLASS_OTHER, 0, s);
       launch_linear_mfma_splitk(cur.data, ab4, FM_CF, h->packed + h->fc_pk, h->params + h->fcb, comb, part,
                                 FM_FC_SPLITS, B, FM_P * FM_CF, F, F + T, s);
@@ -1354,6 +1414,7 @@ struct FmRun {
     Map u3 = conv(u2, ab2, h->c3, CONV_S1);
     float* ab3 = finalize(u3, h->dgw[2], h->dgb[2]);
     if (!dry) {
+      flush_conv(pend, s);
       ConvOutArgs co{};
       co.in = u3.data, co.ab = ab3, co.w = h->params + h->cow, co.bias = h->params + h->cob;
       co.v_out = v_out, co.x_state = x_state, co.dt = dt, co.B = B, co.Cin = 32;
@@ -1439,7 +1500,7 @@ extern "C" void rgfm_fmnet_destroy(rgfm_fmnet* h) {
 
 extern "C" int rgfm_fmnet_workspace_bytes(const rgfm_fmnet* h, int batch, size_t* bytes) {
   if (!h || !bytes || batch < 1) return fail(RGFM_EINVAL, "bad argument");
-  *bytes = fm_eval_bytes(const_cast<rgfm_fmnet*>(h), batch);
+  *bytes = fm_eval_bytes(const_cast<rgfm_fmnet*>(h), batch) + counter_bytes(batch);
   return RGFM_OK;
 }
 
@@ -1447,11 +1508,14 @@ extern "C" int rgfm_fmnet_forward(rgfm_fmnet* h, const float* x, const float* t_
                                   int batch, void* ws, size_t ws_bytes, rgfm_stream_t stream) {
   if (!h || !x || !t_dev || !v_out || !ws) return fail(RGFM_EINVAL, "null argument");
   if (batch < 1 || (t_count != 1 && t_count != batch)) return fail(RGFM_EINVAL, "t_count must be 1 or batch");
-  const size_t need = fm_eval_bytes(h, batch);
+  const size_t need = fm_eval_bytes(h, batch) + counter_bytes(batch);
   if (need > ws_bytes) return fail(RGFM_ENOMEM, "workspace too small: %zu < %zu", ws_bytes, need);
   Bump b;
   b.base = (char*)ws, b.cap = ws_bytes, b.dry = false;
+  unsigned* cnt = reinterpret_cast<unsigned*>(b.f(batch));
+  HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)batch * sizeof(unsigned), (hipStream_t)stream));
   FmRun r{h, batch, &b, (hipStream_t)stream, false, t_dev, t_count, 1, 0};
+  r.fin_counter = cnt;
   int rc = r.run(x, v_out, nullptr, 0.f);
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
@@ -1463,13 +1527,20 @@ extern "C" int rgfm_fmnet_sample_single(rgfm_fmnet* h, float* x_inout, int batch
   if (!h || !x_inout || !ws) return fail(RGFM_EINVAL, "null argument");
   if (batch < 1 || num_steps < 1 || step_begin < 0 || step_end > num_steps || step_begin > step_end)
     return fail(RGFM_EINVAL, "bad step range [%d,%d) of %d", step_begin, step_end, num_steps);
-  const size_t need = fm_eval_bytes(h, batch);
+  const size_t need = fm_eval_bytes(h, batch) + counter_bytes(batch);
   if (need > ws_bytes) return fail(RGFM_ENOMEM, "workspace too small: %zu < %zu", ws_bytes, need);
   const float dt = (float)(1.0 / (double)num_steps);
+  unsigned* cnt = nullptr;
   for (int st = step_begin; st < step_end; ++st) {
     Bump b;
     b.base = (char*)ws, b.cap = ws_bytes, b.dry = false;
+    unsigned* c0 = reinterpret_cast<unsigned*>(b.f(batch));
+    if (!cnt) {
+      cnt = c0;
+      HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)batch * sizeof(unsigned), (hipStream_t)stream));
+    }
     FmRun r{h, batch, &b, (hipStream_t)stream, false, nullptr, 1, num_steps, st};
+    r.fin_counter = cnt;
     int rc = r.run(x_inout, nullptr, x_inout, dt);
     if (rc) return rc;
   }
@@ -1482,7 +1553,7 @@ extern "C" int rgfm_fmnet_sample_pair_workspace_bytes(const rgfm_fmnet* hx, cons
   if (!hx || !hy || !bytes || batch < 1 || n_mc < 0) return fail(RGFM_EINVAL, "bad argument");
   const size_t d = (size_t)FM_S * FM_S;
   size_t total = fm_eval_bytes(const_cast<rgfm_fmnet*>(hx), batch) + fm_eval_bytes(const_cast<rgfm_fmnet*>(hy), batch);
-  total += 2 * ((batch * d * 4 + 255) & ~(size_t)255);
+  total += 2 * ((batch * d * 4 + 255) & ~(size_t)255) + 2 * counter_bytes(batch);
   total += (((size_t)batch * (n_mc > 0 ? n_mc : 1) * 4) + 255) & ~(size_t)255;
   *bytes = total;
   return RGFM_OK;
@@ -1508,16 +1579,22 @@ extern "C" int rgfm_fmnet_sample_pair(rgfm_fmnet* hx, rgfm_fmnet* hy, float* x_i
   float* vx = b.f((size_t)batch * d);
   float* vy = b.f((size_t)batch * d);
   float* logp = b.f((size_t)batch * (n_mc > 0 ? n_mc : 1));
+  unsigned* cnt_x = reinterpret_cast<unsigned*>(b.f(batch));
+  unsigned* cnt_y = reinterpret_cast<unsigned*>(b.f(batch));
+  HIP_TRY(hipMemsetAsync(cnt_x, 0, (size_t)batch * sizeof(unsigned), s));
+  HIP_TRY(hipMemsetAsync(cnt_y, 0, (size_t)batch * sizeof(unsigned), s));
   const size_t mark_x = b.off;
   const size_t mark_y = mark_x + fm_eval_bytes(hx, batch);
   auto eval_x = [&](int i, hipStream_t st, float* v_out, float* x_state, float dt) {
     b.off = mark_x;
     FmRun r{hx, batch, &b, st, false, nullptr, 1, num_steps, step_begin + i};
+    r.fin_counter = cnt_x;
     return r.run(x_inout, v_out, x_state, dt);
   };
   auto eval_y = [&](int i, hipStream_t st, float* v_out, float* y_state, float dt) {
     b.off = mark_y;
     FmRun r{hy, batch, &b, st, false, nullptr, 1, num_steps, step_begin + i};
+    r.fin_counter = cnt_y;
     return r.run(y_inout, v_out, y_state, dt);
   };
   return pair_loop(eval_x, eval_y, x_inout, y_inout, mc_x1, mc_y1, mc_ratios, n_mc, batch, num_steps, gamma, step_begin,

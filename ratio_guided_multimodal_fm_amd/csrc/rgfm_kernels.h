@@ -97,6 +97,16 @@ struct ConvArgs {
   const float* ep_shift;
   float* out;        // NHWC [B][H][W][Cout]
   float* stats_out;  // [B][nparts][Cout][2] or null
+  // Producer-side GroupNorm finalize (conv_mfma_bx3.hip): when fin_ab is set, the LAST wave to deliver
+  // statistics of a sample (arrival counter) computes the scale/shift of the norm that consumes this
+  // output -- cat(this output, fin_stats1's tensor) -- instead of a separate gn_finalize launch.
+  float* fin_ab;             // [B][Cout + fin_C1][2] or null
+  unsigned* fin_counter;     // [B], zero between launches (the finishing wave resets its entry)
+  int fin_expected;          // arrivals per sample
+  const float* fin_stats1;   // partner statistics [B][nparts][fin_C1][2] (same spatial size as the output) or null
+  int fin_C1;
+  const float* fin_gamma;    // [Cout + fin_C1]
+  const float* fin_beta;
   int B, Cout;
   TileGeom g;        // OUTPUT raster tiling
   int halo_px;       // pixels of the staged input tile
@@ -168,6 +178,7 @@ void launch_conv_v3(const ConvArgs& a, int mode, int num_cus, hipStream_t s);
 
 // fp32 conv with operands split into three bf16 planes, on the bf16 matrix cores (conv_mfma_bx3.hip)
 bool conv_bx3_supported(const ConvArgs& a, int mode);
+int conv_bx3_fin_expected(const ConvArgs& a, int mode);  // arrivals per sample for ConvArgs::fin_expected
 int conv_bx3_init();
 void launch_conv_bx3(const ConvArgs& a, int mode, hipStream_t s);
 void launch_pack_conv_bx3(const float* w, void* out, int Cout, int Cin, int taps, hipStream_t s);
