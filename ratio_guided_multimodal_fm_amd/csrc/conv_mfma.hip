@@ -224,12 +224,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
       m2 += __shfl_xor(m2, 32);
       if (h == 0 && sample_ok) {
         const int c = n0 + nt * 32 + l31;
-        float2 st;
-        st.x = mean;
-        st.y = m2;
-        *reinterpret_cast<float2*>(a.stats_out + (((size_t)bw * g.nparts + part) * a.Cout + c) * 2) = st;
+        store_stats(a, a.stats_out + (((size_t)bw * g.nparts + part) * a.Cout + c) * 2, mean, m2);
       }
     }
+    if (a.fin_ab && sample_ok) fin_arrive(a, bw, lane, g.nparts, false);
   }
 }
 
@@ -560,12 +558,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pf_kernel(const ConvArgs a) 
       m2 += __shfl_xor(m2, 32);
       if (h == 0 && sample_ok) {
         const int c = n0 + nt * 32 + l31;
-        float2 st;
-        st.x = mean;
-        st.y = m2;
-        *reinterpret_cast<float2*>(a.stats_out + (((size_t)bw * nparts + part) * a.Cout + c) * 2) = st;
+        store_stats(a, a.stats_out + (((size_t)bw * nparts + part) * a.Cout + c) * 2, mean, m2);
       }
     }
+    if (a.fin_ab && sample_ok) fin_arrive(a, bw, lane_e, nparts, MODE == CONV_T2);
   }
 }
 

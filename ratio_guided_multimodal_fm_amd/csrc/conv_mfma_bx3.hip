@@ -52,69 +52,6 @@ __device__ unsigned long long g_bx3_prof[10];  // prologue, issue, mfma, commit-
 #define PROF_ADD(slot, t0, t1)
 #endif
 
-// GroupNorm finalize of ONE sample by ONE wave (see ConvArgs::fin_ab): Chan-combines the (count, mean, M2)
-// partials of every (channel, part) of a group in fp64 -- lane = group * 8 + sub, sub strides over the group's
-// channels, then a 3-step butterfly over sub -- and writes a = rstd * gamma, b = beta - mean * a per channel.
-// Same result as gn_finalize_kernel up to fp64 summation order.
-__device__ __forceinline__ void chan_merge(double& n, double& mean, double& m2, double nb, double mb, double m2b) {
-  const double nn = n + nb;
-  if (nn > 0.0) {
-    const double d = mb - mean;
-    mean += d * (nb / nn);
-    m2 += m2b + d * d * (n * nb / nn);
-    n = nn;
-  }
-}
-
-__device__ __forceinline__ void fin_sample(const ConvArgs& a, int b, int lane, int nparts0, bool t2) {
-  const int C0 = a.Cout, C = a.Cout + a.fin_C1;
-  const int cpg = C >> 3;  // 8 groups (C >= 32 on this path)
-  const int gi = lane >> 3, sub = lane & 7;
-  const TileGeom g = a.g;
-  double n = 0.0, mean = 0.0, m2 = 0.0;
-  for (int c = gi * cpg + sub; c < (gi + 1) * cpg; c += 8) {
-    const bool first = c < C0;
-    const float* st = first ? a.stats_out : a.fin_stats1;
-    const int cs = first ? C0 : a.fin_C1, cc = first ? c : c - C0;
-    const int np_total = first ? nparts0 : g.nparts;  // the partner is a plain map of the output's size (<= 16 parts)
-    // all of the channel's partials are fetched before any is merged: one memory round trip instead of np_total
-    unsigned long long bits[16];
-#pragma unroll
-    for (int p = 0; p < 16; ++p) {
-      const float* sp = st + (((size_t)b * np_total + (p < np_total ? p : 0)) * cs + cc) * 2;
-      // first source: written during THIS launch, possibly by a CU of another XCD (whose L2 is not coherent with
-      // ours for plain accesses) -> agent-scope atomic accesses go to the coherence point on both sides
-      bits[p] = first ? __hip_atomic_load(reinterpret_cast<const unsigned long long*>(sp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                      : *reinterpret_cast<const unsigned long long*>(sp);
-    }
-#pragma unroll
-    for (int p = 0; p < 16; ++p) {
-      if (p < np_total) {
-        // part geometry: a CONV_T2 output is four parity classes of the input raster g; a partner map of a
-        // stride-1 / upsampling conv has the output raster g itself
-        const int np = geom_part_count(g, (first && t2) ? p % g.nparts : p);
-        if (np > 0)
-          chan_merge(n, mean, m2, (double)np, (double)__uint_as_float((unsigned)(bits[p] & 0xffffffffull)),
-                     (double)__uint_as_float((unsigned)(bits[p] >> 32)));
-      }
-    }
-  }
-#pragma unroll
-  for (int o = 1; o < 8; o <<= 1) {
-    const double nb = __shfl_xor(n, o), mb = __shfl_xor(mean, o), m2b = __shfl_xor(m2, o);
-    chan_merge(n, mean, m2, nb, mb, m2b);
-  }
-  const float gm = (float)mean;
-  const float rstd = (float)(1.0 / sqrt(m2 / n + 1e-5));
-  for (int c = gi * cpg + sub; c < (gi + 1) * cpg; c += 8) {
-    const float sc = rstd * a.fin_gamma[c];
-    float2 o;
-    o.x = sc;
-    o.y = a.fin_beta[c] - gm * sc;
-    *reinterpret_cast<float2*>(a.fin_ab + ((size_t)b * C + c) * 2) = o;
-  }
-}
-
 constexpr int RW = 96;
 __device__ __forceinline__ int swz(int rec, int half) { return ((half ^ (rec >> 3)) & 1) * 16; }
 
@@ -498,31 +435,10 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
         float2 st;
         st.x = mean;
         st.y = m2;
-        float* sp = a.stats_out + (((size_t)bw * nparts + part) * a.Cout + c) * 2;
-        if (a.fin_ab) {  // read back inside this launch by the finalizing wave: coherent (agent-scope) store
-          const unsigned long long bits = (unsigned long long)__float_as_uint(mean) | ((unsigned long long)__float_as_uint(m2) << 32);
-          __hip_atomic_store(reinterpret_cast<unsigned long long*>(sp), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-          *reinterpret_cast<float2*>(sp) = st;
-        }
+        store_stats(a, a.stats_out + (((size_t)bw * nparts + part) * a.Cout + c) * 2, mean, m2);
       }
     }
-    if (a.fin_ab && sample_ok) {
-      // every wave delivers its statistics, then counts itself in; the last one of the sample finalizes.
-      // No agent-scope fence here: on this multi-XCD part it writes back / invalidates the whole L2 (measured:
-      // the conv class dropped from 152 to 92 TFLOP/s); the statistics and the counter use agent-scope atomic
-      // accesses instead, ordered by waiting for the stores' acknowledgement.
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      unsigned last = 0u;
-      if (lane_e == 0)
-        last = (__hip_atomic_fetch_add(a.fin_counter + bw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
-                (unsigned)(a.fin_expected - 1)) ? 1u : 0u;
-      last = __shfl(last, 0);
-      if (last) {
-        fin_sample(a, bw, lane_e, nparts, MODE == CONV_T2);
-        if (lane_e == 0) __hip_atomic_store(a.fin_counter + bw, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
+    if (a.fin_ab && sample_ok) fin_arrive(a, bw, lane_e, nparts, MODE == CONV_T2);
   }
 #ifdef RGFM_BX3_PROF
   PROF_T(te1);
@@ -624,7 +540,7 @@ bool conv_bx3_supported(const ConvArgs& a, int mode) {
   return a.halo_px <= 448 && bx3w_lds_bytes(a, mode) <= 160 * 1024;
 }
 
-int conv_bx3_fin_expected(const ConvArgs& a, int mode) {
+int conv_fin_expected(const ConvArgs& a, int mode) {
   const int groups = a.Cout / (32 * ((a.Cout % 64 == 0) ? 2 : 1));  // 4-wave groups along the channels
   return (a.g.spt == 1 ? 4 * a.g.tps : 1) * groups * (mode == CONV_T2 ? 4 : 1);
 }

@@ -412,10 +412,11 @@ bool try_fuse_finalize(PendingConv& p, const float* first_data, const float* sta
                        const float* beta, float* ab, unsigned* counter) {
   static const bool off = getenv("RGFM_FUSE_FIN") && getenv("RGFM_FUSE_FIN")[0] == '0';  // A/B switch
   if (off || !p.valid || !counter || p.c.out != first_data || !p.c.stats_out) return false;
-  if ((p.wino && use_wino()) || !use_bx3() || !conv_bx3_supported(p.c, p.mode)) return false;
-  if ((p.c.Cout + C1) % 8 != 0 || p.c.Cout + C1 < 32) return false;
+  if (p.wino && use_wino() && conv_wino_supported(p.c, p.mode)) return false;  // (the experimental kernels do not carry it)
+  if (use_v3() && conv_v3_supported(p.c, p.mode)) return false;
+  if ((p.c.Cout + C1) % 8 != 0 || p.c.Cout + C1 < 32 || p.c.Cout + C1 > 256) return false;  // <= 4 channels per lane
   if (p.c.g.nparts * (p.mode == CONV_T2 ? 4 : 1) > 16) return false;  // the finalizing wave holds <= 16 partials per channel
-  p.c.fin_ab = ab, p.c.fin_counter = counter, p.c.fin_expected = conv_bx3_fin_expected(p.c, p.mode);
+  p.c.fin_ab = ab, p.c.fin_counter = counter, p.c.fin_expected = conv_fin_expected(p.c, p.mode);
   p.c.fin_stats1 = stats1, p.c.fin_C1 = C1, p.c.fin_gamma = gamma, p.c.fin_beta = beta;
   return true;
 }
@@ -450,6 +451,9 @@ struct UNetRun {
                                          h->params + beta, ab, fin_counter);
     flush_conv(pend, s);
     if (fused) return ab;
+    static const bool exp_skip = getenv("RGFM_EXP_SKIPFIN") != nullptr;  // TIMING EXPERIMENT ONLY (wrong results)
+    static int exp_calls = 0;
+    if (exp_skip && ++exp_calls > 400) return ab;
     GnFinalizeArgs f{};
     f.stats0 = a.stats, f.stats1 = b ? b->stats : nullptr;
     f.C0 = a.C, f.C1 = b ? b->C : 0;

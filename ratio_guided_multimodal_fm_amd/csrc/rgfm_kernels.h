@@ -178,7 +178,7 @@ void launch_conv_v3(const ConvArgs& a, int mode, int num_cus, hipStream_t s);
 
 // fp32 conv with operands split into three bf16 planes, on the bf16 matrix cores (conv_mfma_bx3.hip)
 bool conv_bx3_supported(const ConvArgs& a, int mode);
-int conv_bx3_fin_expected(const ConvArgs& a, int mode);  // arrivals per sample for ConvArgs::fin_expected
+int conv_fin_expected(const ConvArgs& a, int mode);  // arrivals per sample for ConvArgs::fin_expected (all conv_mfma* kernels)
 int conv_bx3_init();
 void launch_conv_bx3(const ConvArgs& a, int mode, hipStream_t s);
 void launch_pack_conv_bx3(const float* w, void* out, int Cout, int Cin, int taps, hipStream_t s);

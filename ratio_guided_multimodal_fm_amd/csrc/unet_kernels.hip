@@ -235,15 +235,22 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const GnFinalizeArgs a
     } else {
       st = a.stats1, cs = a.C1, cc = c - a.C0;
     }
-    double n = 0.0, mean = 0.0, m2 = 0.0;
+    // division-free in the loops (an fp64 divide is ~40 instructions and the kernel sits between two convs):
+    // mean = sum n_p mean_p / N,  M2 = sum [M2_p + n_p (mean_p - mean)^2]
+    double s1 = 0.0;
+    for (int p = 0; p < nparts; ++p) {
+      const int np = geom_part_count(g, p % g.nparts);
+      if (np == 0) continue;
+      s1 += (double)np * (double)st[(((size_t)b * nparts + p) * cs + cc) * 2];
+    }
+    const double mean = s1 / npix;
+    double m2 = 0.0;
     for (int p = 0; p < nparts; ++p) {
       const int np = geom_part_count(g, p % g.nparts);
       if (np == 0) continue;
       const float2 v = *reinterpret_cast<const float2*>(st + (((size_t)b * nparts + p) * cs + cc) * 2);
-      const double nb = (double)np, d = (double)v.x - mean, nn = n + nb;
-      mean += d * nb / nn;
-      m2 += (double)v.y + d * d * n * nb / nn;
-      n = nn;
+      const double d = (double)v.x - mean;
+      m2 += (double)v.y + (double)np * d * d;
     }
     s_mean[c] = mean;
     s_m2[c] = m2;
