@@ -72,7 +72,9 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
   PROF_T(tp0);
   char* sA = smem3;
   char* sB = smem3 + NA * a.halo_px * RW;
-  float* sAB = reinterpret_cast<float*>(sB + NTAPS * NBLK * NG * RW);  // [NA * spt][16][2]
+  float* sAB = reinterpret_cast<float*>(sB + NTAPS * NBLK * NG * RW);  // [NA * spt][16][2]   (external `ab` path)
+  float* sG = sAB + 256;                                                // [NA * spt][8][2] group (mean, rstd)
+  float* sTab = sG + 128;                                               // [NA * spt][cin][2] (consumer-side GroupNorm)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = wave >> 2, seg = wave & 3;
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
       rb[j] = *(const bx_gf32x4*)(w0 + (size_t)(it < nbit ? it : 0) * 16);
 #endif
     }
-    if (!skip && a.ab) {
+    if (!skip && a.ab && !a.gn_stats0) {
       const size_t o = ab_b >= 0 ? ((size_t)ab_b * cin + c + 2 * (tid & 7)) * 2 : 0;
       rab = *(const bx_gf32x4*)(a.ab + o);
     }
@@ -285,9 +287,11 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
 
   auto commit = [&](int ch) {
     const bool skip = ch >= nch_main;
-    const bool xform = !skip && (a.ab != nullptr);
+    const int chc = ch * KC;  // first channel of the chunk in the concatenated input
+    const bool gnk = a.gn_stats0 != nullptr;
+    const bool xform = !skip && (a.ab != nullptr || gnk);
     PROF_T(tc0);
-    if (xform && tid < NA * g.spt * 8) *reinterpret_cast<f32x4*>(sAB + (ab_slot * 8 + (tid & 7)) * 4) = rab;
+    if (xform && !gnk && tid < NA * g.spt * 8) *reinterpret_cast<f32x4*>(sAB + (ab_slot * 8 + (tid & 7)) * 4) = rab;
     __syncthreads();
     PROF_T(tc1);
     PROF_ADD(3, tc0, tc1);
@@ -299,8 +303,11 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
         if (!okj) v = f32x4{0.f, 0.f, 0.f, 0.f};
         if (xform && okj) {
           const int s = (smask >> (3 * j)) & 7u;
-          const f32x4 e0 = *reinterpret_cast<const f32x4*>(sAB + (s * 16 + q4 * 4) * 2);
-          const f32x4 e1 = *reinterpret_cast<const f32x4*>(sAB + (s * 16 + q4 * 4) * 2 + 4);
+          // scale/shift of the item's 4 channels: this chunk's slice of the block-lifetime table (consumer-side
+          // GroupNorm; slot = (s >> 2) * spt + (s & 3)) or the per-chunk sAB copy of the external `ab`
+          const float* ep = gnk ? sTab + ((((s >> 2) * g.spt + (s & 3)) * cin + chc + q4 * 4) * 2) : sAB + (s * 16 + q4 * 4) * 2;
+          const f32x4 e0 = *reinterpret_cast<const f32x4*>(ep);
+          const f32x4 e1 = *reinterpret_cast<const f32x4*>(ep + 4);
           v.x = silu_fast(e0.x * v.x + e0.y);
           v.y = silu_fast(e0.z * v.y + e0.w);
           v.z = silu_fast(e1.x * v.z + e1.y);
@@ -331,6 +338,65 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
 
   PROF_T(tp1);
   PROF_ADD(0, tp0, tp1);
+  if (a.gn_stats0) {
+    // ---- consumer-side GroupNorm: scale/shift of this block's sample(s) from the producers' partial statistics,
+    // before chunk 0's prefetch registers come alive (with them the partials would spill).  Wave w owns table row
+    // w (= ga * spt + s, the slot of smask); lane = group * 8 + sub, sub strides over the group's channels; all of a
+    // lane's <= 4 x 16 partials are fetched in one round trip, reduced in fp64 without divisions in the loop:
+    //   N = sum n_p, S1 = sum n_p mean_p, S2 = sum [M2_p + n_p mean_p^2]  ->  mean = S1 / N, var = S2 / N - mean^2
+    if (wave < NA * g.spt) {
+      const int ga = (g.spt == 1) ? wave : (wave >> 2), sl = (g.spt == 1) ? 0 : (wave & 3);
+      const int b = (ga ? tb0_[1] : tb0_[0]) + sl;
+      const TileGeom gg = a.gn_g;
+      const int cpg = cin >> 3, gi = lane >> 3, sub = lane & 7;
+      float gam[4], bet[4];
+      const bool bok = b < a.B;
+      double n = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll 1
+      for (int k = 0; k < 4; ++k) {  // one channel (16 partials) per round trip: more at once spills
+        const int c = gi * cpg + sub + 8 * k;
+        const bool have = bok && sub + 8 * k < cpg;
+        const bool first = !have || c < a.C0;  // (no k-th channel: entry 0 of the first source, never used)
+        const float* st = first ? a.gn_stats0 : a.gn_stats1;
+        const int cs = first ? a.C0 : a.C1, cc = have ? (first ? c : c - a.C0) : 0;
+        const int npt = first ? a.gn_nparts0 : gg.nparts;
+        const size_t bb = bok ? (size_t)b : 0;
+        float2 v[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+          v[p] = *reinterpret_cast<const float2*>(st + ((bb * npt + (p < npt ? p : 0)) * cs + cc) * 2);
+        const float gv = a.gn_gamma[have ? c : 0], bv = a.gn_beta[have ? c : 0];
+        if (k == 0) gam[0] = gv, bet[0] = bv;
+        else if (k == 1) gam[1] = gv, bet[1] = bv;
+        else if (k == 2) gam[2] = gv, bet[2] = bv;
+        else gam[3] = gv, bet[3] = bv;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+          const double np = (have && p < npt) ? (double)geom_part_count(gg, p % gg.nparts) : 0.0;
+          const double mp = (double)v[p].x;
+          n += np;
+          s1 += np * mp;
+          s2 += np > 0.0 ? (double)v[p].y + np * mp * mp : 0.0;
+        }
+      }
+      n = sub_sum(n), s1 = sub_sum(s1), s2 = sub_sum(s2);
+      const double mean = n > 0.0 ? s1 / n : 0.0;
+      const double var = n > 0.0 ? s2 / n - mean * mean : 0.0;
+      const float gm = (float)mean;
+      const float rstd = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + 1e-5));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (sub + 8 * k < cpg) {
+          const float sc = rstd * gam[k];
+          float2 o;
+          o.x = sc;
+          o.y = bet[k] - gm * sc;
+          *reinterpret_cast<float2*>(sTab + ((size_t)wave * cin + gi * cpg + sub + 8 * k) * 2) = o;
+        }
+      }
+    }
+    // (visible to every wave after the barrier that opens commit(0))
+  }
   issue(0);
   commit(0);
   for (int ch = 0; ch < ntot; ++ch) {
@@ -528,7 +594,9 @@ static size_t bx3w_lds_bytes(const ConvArgs& a, int mode) {
   const int nt = (a.Cout % 64 == 0) ? 2 : 1;
   const int ntaps = mode == CONV_T2 ? 4 : 9;
   const bool pn = bx3_pairn(a);
-  return (size_t)((pn ? 1 : 2) * a.halo_px + ntaps * 32 * nt * (pn ? 2 : 1)) * RW + 2 * 128 * sizeof(float);
+  size_t bytes = (size_t)((pn ? 1 : 2) * a.halo_px + ntaps * 32 * nt * (pn ? 2 : 1)) * RW + (256 + 128) * sizeof(float);
+  if (a.gn_stats0) bytes += (size_t)(pn ? 1 : 2) * a.g.spt * (a.C0 + a.C1) * 2 * sizeof(float);  // scale/shift table
+  return bytes;
 }
 bool conv_bx3_supported(const ConvArgs& a, int mode) {
   if (mode == CONV_S2 || !a.wpk3 || a.ep_scale) return false;  // (the BatchNorm+SiLU epilogue of the ratio nets stays on conv_mfma.hip)
@@ -538,6 +606,13 @@ bool conv_bx3_supported(const ConvArgs& a, int mode) {
   const size_t cmax = (size_t)(a.C0 > a.C1 ? a.C0 : a.C1) > (size_t)a.Cout ? (size_t)(a.C0 > a.C1 ? a.C0 : a.C1) : (size_t)a.Cout;
   if (px_in >= (1u << 24) || px_out >= (1u << 24) || (px_in > px_out ? px_in : px_out) * cmax >= (1ull << 32)) return false;
   return a.halo_px <= 448 && bx3w_lds_bytes(a, mode) <= 160 * 1024;
+}
+
+bool conv_bx3_gn_supported(const ConvArgs& a, int mode) {
+  const int cin = a.C0 + a.C1;
+  if (!a.gn_stats0 || cin < 32 || cin % 8 != 0 || cin > 256) return false;  // <= 4 channels per lane in the prologue
+  if (a.gn_nparts0 > 16 || a.gn_g.nparts > 16) return false;  // the prologue holds <= 16 partials per channel
+  return conv_bx3_supported(a, mode);                         // (its LDS check includes the table)
 }
 
 int conv_fin_expected(const ConvArgs& a, int mode) {

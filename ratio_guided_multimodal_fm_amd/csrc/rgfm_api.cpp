@@ -410,7 +410,8 @@ void flush_conv(PendingConv& p, hipStream_t s) {
 // true when `p` can take the finalize of cat(its output, partner) itself
 bool try_fuse_finalize(PendingConv& p, const float* first_data, const float* stats1, int C1, const float* gamma,
                        const float* beta, float* ab, unsigned* counter) {
-  static const bool off = getenv("RGFM_FUSE_FIN") && getenv("RGFM_FUSE_FIN")[0] == '0';  // A/B switch
+  const char* e = getenv("RGFM_FUSE_FIN");  // A/B switch (read per call)
+  const bool off = e && e[0] == '0';
   if (off || !p.valid || !counter || p.c.out != first_data || !p.c.stats_out) return false;
   if (p.wino && use_wino() && conv_wino_supported(p.c, p.mode)) return false;  // (the experimental kernels do not carry it)
   if (use_v3() && conv_v3_supported(p.c, p.mode)) return false;
@@ -420,6 +421,28 @@ bool try_fuse_finalize(PendingConv& p, const float* first_data, const float* sta
   p.c.fin_stats1 = stats1, p.c.fin_C1 = C1, p.c.fin_gamma = gamma, p.c.fin_beta = beta;
   return true;
 }
+
+// RGFM_GN=table: every GroupNorm is finalized into an [B][C][2] scale/shift array (by the producing conv's last
+// wave, or a gn_finalize launch); default: the split-bf16 conv derives it in its own prologue from the partial
+// statistics (ConvArgs::gn_*), the table path remains for the kernels that cannot (conv_out, stride-2, RGFM_CONV=f32).
+bool gn_consumer_side() {
+  const char* e = getenv("RGFM_GN");
+  return !(e && strcmp(e, "table") == 0);
+}
+
+// Tries the consumer-side norm for conv `c`; on failure the gn_* fields are cleared and the caller supplies `ab`.
+bool try_consumer_gn(ConvArgs& c, int mode, const float* wino, const float* stats0, const float* stats1, int nparts0,
+                     const TileGeom& gg, const float* gamma, const float* beta) {
+  c.gn_stats0 = stats0, c.gn_stats1 = stats1, c.gn_gamma = gamma, c.gn_beta = beta, c.gn_nparts0 = nparts0, c.gn_g = gg;
+  const bool ok = gn_consumer_side() && use_bx3() && !(wino && use_wino() && conv_wino_supported(c, mode)) &&
+                  conv_bx3_gn_supported(c, mode);
+  if (!ok) c.gn_stats0 = c.gn_stats1 = c.gn_gamma = c.gn_beta = nullptr;
+  return ok;
+}
+
+struct NormRef {  // a GroupNorm in front of a conv: parameters (offsets into the blob)
+  size_t gamma, beta;
+};
 
 struct UNetRun {
   rgfm_unet* h;
@@ -443,17 +466,14 @@ struct UNetRun {
   void record(const Tensor& t) {
     if (!dry && h->trace) h->acts.push_back({t.data, t.C, t.S, false});
   }
-  float* finalize(const Tensor& a, const Tensor* b, size_t gamma, size_t beta) {
+  float* finalize(const Tensor& a, const Tensor* b, size_t gamma, size_t beta, float* ab = nullptr) {
     const int C = a.C + (b ? b->C : 0);
-    float* ab = ws->f((size_t)B * C * 2);
+    if (!ab) ab = ws->f((size_t)B * C * 2);
     if (dry) return ab;
     const bool fused = try_fuse_finalize(pend, a.data, b ? b->stats : nullptr, b ? b->C : 0, h->params + gamma,
                                          h->params + beta, ab, fin_counter);
     flush_conv(pend, s);
     if (fused) return ab;
-    static const bool exp_skip = getenv("RGFM_EXP_SKIPFIN") != nullptr;  // TIMING EXPERIMENT ONLY (wrong results)
-    static int exp_calls = 0;
-    if (exp_skip && ++exp_calls > 400) return ab;
     GnFinalizeArgs f{};
     f.stats0 = a.stats, f.stats1 = b ? b->stats : nullptr;
     f.C0 = a.C, f.C1 = b ? b->C : 0;
@@ -465,11 +485,13 @@ struct UNetRun {
     return ab;
   }
   // generic 3x3 conv launch
-  Tensor conv(const Tensor& a, const Tensor* b, const float* ab, const ConvW& w, int mode, const float* temb,
+  Tensor conv(const Tensor& a, const Tensor* b, const NormRef* norm, const ConvW& w, int mode, const float* temb,
               int res_mode, const Tensor* r0, const Tensor* r1, const ConvW* sk) {
     const int So = mode == CONV_S2 ? a.S / 2 : (mode == CONV_UP2 ? a.S * 2 : a.S);
     Tensor o = new_tensor(w.cout, So);
+    float* ab_buf = norm ? ws->f((size_t)B * (a.C + (b ? b->C : 0)) * 2) : nullptr;  // used by the table path only
     if (dry) return o;
+    const float* ab = nullptr;
     ConvArgs c{};
     c.in0 = a.data, c.in1 = b ? b->data : nullptr;
     c.C0 = a.C, c.C1 = b ? b->C : 0;
@@ -490,18 +512,24 @@ struct UNetRun {
     c.g = make_geom(So, So);
     c.halo_px = mode == CONV_S2 ? c.g.spt * (2 * c.g.th + 1) * (2 * c.g.W + 1) : c.g.spt * (c.g.th + 2) * (c.g.W + 2);
     const int kprod = 9 * w.cin + (res_mode == 2 ? sk->cin : 0);
+    const float* wino = w.has_wino ? h->wino + w.w_wino : nullptr;
+    if (norm) {
+      const TileGeom gg = make_geom(a.S, a.S);
+      if (!try_consumer_gn(c, mode, wino, a.stats, b ? b->stats : nullptr, gg.nparts, gg, h->params + norm->gamma,
+                           h->params + norm->beta))
+        c.ab = finalize(a, b, norm->gamma, norm->beta, ab_buf);  // (may attach itself to the pending producer)
+    }
     flush_conv(pend, s);
-    pend.valid = true, pend.c = c, pend.mode = mode, pend.wino = w.has_wino ? h->wino + w.w_wino : nullptr;
+    pend.valid = true, pend.c = c, pend.mode = mode, pend.wino = wino;
     pend.flops = conv_flops(B, So * So, w.cout, kprod);
     return o;
   }
   // ResBlock.forward (unet_flexible.py:71-85)
   Tensor resblock(const ResW& r, const Tensor& a, const Tensor* b) {
-    float* ab1 = finalize(a, b, r.n1w, r.n1b);
-    Tensor h1 = conv(a, b, ab1, r.c1, CONV_S1, dry ? nullptr : temb_row + r.temb_off, 0, nullptr, nullptr, nullptr);
+    const NormRef n1{r.n1w, r.n1b}, n2{r.n2w, r.n2b};
+    Tensor h1 = conv(a, b, &n1, r.c1, CONV_S1, dry ? nullptr : temb_row + r.temb_off, 0, nullptr, nullptr, nullptr);
     record(h1);
-    float* ab2 = finalize(h1, nullptr, r.n2w, r.n2b);
-    Tensor o = conv(h1, nullptr, ab2, r.c2, CONV_S1, nullptr, r.has_skip ? 2 : 1, &a, b, r.has_skip ? &r.sk : nullptr);
+    Tensor o = conv(h1, nullptr, &n2, r.c2, CONV_S1, nullptr, r.has_skip ? 2 : 1, &a, b, r.has_skip ? &r.sk : nullptr);
     record(o);
     return o;
   }
@@ -1345,8 +1373,8 @@ struct FmRun {
     m.stats = ws->f((size_t)B * g.nparts * rep * C * 2);
     return m;
   }
-  float* finalize(const Map& a, size_t gamma, size_t beta) {
-    float* ab = ws->f((size_t)B * a.C * 2);
+  float* finalize(const Map& a, size_t gamma, size_t beta, float* ab = nullptr) {
+    if (!ab) ab = ws->f((size_t)B * a.C * 2);
     if (dry) return ab;
     const bool fused = try_fuse_finalize(pend, a.data, nullptr, 0, h->params + gamma, h->params + beta, ab, fin_counter);
     flush_conv(pend, s);
@@ -1361,18 +1389,26 @@ struct FmRun {
     launch_gn_finalize(f, s);
     return ab;
   }
-  Map conv(const Map& a, const float* ab, const ConvW& w, int mode) {
+  Map conv(const Map& a, const NormRef* norm, const ConvW& w, int mode) {
     const int So = mode == CONV_S2 ? (a.S + 1) / 2 : (mode == CONV_T2 ? a.S * 2 : a.S);
     Map o = new_map(w.cout, So, mode == CONV_T2 ? 4 : 1);
+    float* ab_buf = norm ? ws->f((size_t)B * a.C * 2) : nullptr;  // used by the table path only
     if (dry) return o;
     ConvArgs c{};
-    c.in0 = a.data, c.C0 = a.C, c.Hin = c.Win = a.S, c.ab = ab;
+    c.in0 = a.data, c.C0 = a.C, c.Hin = c.Win = a.S, c.ab = nullptr;
     c.wpk = h->packed + w.w_pk, c.wpk3 = h->packed3 + w.w_bx3, c.bias = h->params + w.b;
     c.out = o.data, c.stats_out = o.stats, c.B = B, c.Cout = w.cout;
     const int sg = mode == CONV_T2 ? a.S : So;  // raster the tiles walk
     c.g = make_geom(sg, sg);
     c.halo_px = mode == CONV_S2 ? c.g.spt * (2 * c.g.th + 1) * (2 * c.g.W + 1) : c.g.spt * (c.g.th + 2) * (c.g.W + 2);
     const double fl = mode == CONV_T2 ? conv_flops(B, 4 * sg * sg, w.cout, 4 * w.cin) : conv_flops(B, So * So, w.cout, 9 * w.cin);
+    if (norm) {
+      const int gs = a.rep == 4 ? a.S / 2 : a.S;  // raster the statistics parts of `a` refer to
+      const TileGeom gg = make_geom(gs, gs);
+      if (!try_consumer_gn(c, mode, nullptr, a.stats, nullptr, gg.nparts * a.rep, gg, h->params + norm->gamma,
+                           h->params + norm->beta))
+        c.ab = finalize(a, norm->gamma, norm->beta, ab_buf);
+    }
     flush_conv(pend, s);
     pend.valid = true, pend.c = c, pend.mode = mode, pend.wino = nullptr, pend.flops = fl;
     return o;
@@ -1392,8 +1428,8 @@ struct FmRun {
     }
     const int modes[3] = {CONV_S2, CONV_S2, CONV_S1};
     for (int i = 0; i < 3; ++i) {
-      float* ab = finalize(cur, h->egw[i], h->egb[i]);
-      cur = conv(cur, ab, h->ec[i], modes[i]);
+      const NormRef nr{h->egw[i], h->egb[i]};
+      cur = conv(cur, &nr, h->ec[i], modes[i]);
     }
     float* ab4 = finalize(cur, h->egw[3], h->egb[3]);
     float* comb = ws->f((size_t)B * (F + T));  // torch.cat([features, t_emb], dim=1) (:111)
@@ -1411,11 +1447,10 @@ struct FmRun {
     }
     Map m0;
     m0.data = d0, m0.C = FM_CF, m0.S = 7;
+    const NormRef g1{h->dgw[0], h->dgb[0]}, g2{h->dgw[1], h->dgb[1]};
     Map u1 = conv(m0, nullptr, h->d1, CONV_T2);
-    float* ab1 = finalize(u1, h->dgw[0], h->dgb[0]);
-    Map u2 = conv(u1, ab1, h->d2, CONV_T2);
-    float* ab2 = finalize(u2, h->dgw[1], h->dgb[1]);
-    Map u3 = conv(u2, ab2, h->c3, CONV_S1);
+    Map u2 = conv(u1, &g1, h->d2, CONV_T2);
+    Map u3 = conv(u2, &g2, h->c3, CONV_S1);
     float* ab3 = finalize(u3, h->dgw[2], h->dgb[2]);
     if (!dry) {
       flush_conv(pend, s);

@@ -78,6 +78,15 @@ struct ConvArgs {
   int C0, C1;        // channels of in0 / in1 (C1 = 0: single source)
   int Hin, Win;      // spatial size of the sources
   const float* ab;   // [B][C0+C1][2] GroupNorm scale/shift (then SiLU) applied on load; null = raw
+  // Consumer-side GroupNorm (conv_mfma_bx3.hip): instead of `ab`, the partial statistics of the input map(s)
+  // themselves -- every workgroup derives the scale/shift of its own sample(s) in its prologue, so no finalize
+  // launch (or producer-side finalize) sits between two convs.
+  const float* gn_stats0;  // [B][gn_nparts0][C0][2] statistics of in0 (null: use `ab`)
+  const float* gn_stats1;  // [B][gn_g.nparts][C1][2] statistics of in1 or null
+  const float* gn_gamma;   // [C0 + C1]
+  const float* gn_beta;
+  int gn_nparts0;          // parts of in0: gn_g.nparts, or 4 x that when in0 was written by a CONV_T2 launch
+  TileGeom gn_g;           // tiling of the raster the parts refer to (part sizes)
   const float* wpk;  // packed 3x3 weights  [Cout/(32NT)][Cin/16][9][32NT][16]
   const void* wpk3;  // the same weights as three bf16 planes [..][9][32NT][3][16] (conv_mfma_bx3.hip) or null
   const void* wskip3;
@@ -178,6 +187,7 @@ void launch_conv_v3(const ConvArgs& a, int mode, int num_cus, hipStream_t s);
 
 // fp32 conv with operands split into three bf16 planes, on the bf16 matrix cores (conv_mfma_bx3.hip)
 bool conv_bx3_supported(const ConvArgs& a, int mode);
+bool conv_bx3_gn_supported(const ConvArgs& a, int mode);  // a.gn_* filled: can the kernel take the norm itself?
 int conv_fin_expected(const ConvArgs& a, int mode);  // arrivals per sample for ConvArgs::fin_expected (all conv_mfma* kernels)
 int conv_bx3_init();
 void launch_conv_bx3(const ConvArgs& a, int mode, hipStream_t s);

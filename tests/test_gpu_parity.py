@@ -330,12 +330,16 @@ def test_full_size_properties(dev):
     assert maxdiff(ya[rows].cpu().numpy(), oy) < TOL_SAMPLER
 
 
-@pytest.mark.parametrize("env", [{"RGFM_CONV": "f32"}, {"RGFM_CONV": "f32", "RGFM_WINO": "1"}, {"RGFM_CONV": "v3"}])
+@pytest.mark.parametrize("env", [{"RGFM_CONV": "f32"}, {"RGFM_CONV": "f32", "RGFM_WINO": "1"}, {"RGFM_CONV": "v3"},
+                                 {"RGFM_GN": "table"}, {"RGFM_GN": "table", "RGFM_FUSE_FIN": "0"},
+                                 {"RGFM_CONV": "f32", "RGFM_FUSE_FIN": "0"}])
 @pytest.mark.parametrize("tag,B", [("svhn", 5), ("mnist32", 3)])
 def test_experimental_conv_variants_keep_parity(dev, env, tag, B, monkeypatch):
     """The alternative conv paths (exact-fp32 MFMA: RGFM_CONV=f32; with Winograd F(2x2,3x3): + RGFM_WINO=1;
-    persistent one-block-per-CU fp32 kernel: RGFM_CONV=v3; all read per launch) must stay inside the same
-    tolerance as the default split-bf16 path."""
+    persistent one-block-per-CU fp32 kernel: RGFM_CONV=v3; all read per launch) and the alternative GroupNorm
+    plumbing (RGFM_GN=table: scale/shift arrays written by the producing conv's last wave, or -- with
+    RGFM_FUSE_FIN=0 -- by gn_finalize launches, instead of the consumer conv's prologue) must stay inside the
+    same tolerance as the default path."""
     m = make_module(tag, dev)
     desc, blob = oracle_net(tag)
     x = torch.randn(B, *SHAPES[tag], generator=torch.Generator().manual_seed(5))
