@@ -352,8 +352,9 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
       float gam[4], bet[4];
       const bool bok = b < a.B;
       double n = 0.0, s1 = 0.0, s2 = 0.0;
+      const int kmax = (cpg + 7) >> 3;  // channels per lane (wave-uniform)
 #pragma unroll 1
-      for (int k = 0; k < 4; ++k) {  // one channel (16 partials) per round trip: more at once spills
+      for (int k = 0; k < kmax; ++k) {  // one channel (16 partials) per round trip: more at once spills
         const int c = gi * cpg + sub + 8 * k;
         const bool have = bok && sub + 8 * k < cpg;
         const bool first = !have || c < a.C0;  // (no k-th channel: entry 0 of the first source, never used)
