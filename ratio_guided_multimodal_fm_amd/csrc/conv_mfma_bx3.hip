@@ -57,7 +57,11 @@ __device__ __forceinline__ int swz(int rec, int half) { return ((half ^ (rec >> 
 
 template <int NT, int MODE, bool PAIRN>
 __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a, const int num_tiles) {
-  constexpr int NTAPS = (MODE == CONV_T2) ? 4 : 9;
+  // CONV_S2 (3x3, stride 2, pad 1): the input is read as its four pixel-parity phases (a, b) = (row & 1, col & 1),
+  // each a plane of the OUTPUT's size; output (r, x) takes phase (a, b) at plane offsets dr in {-1 (a = 1 only), 0},
+  // dx likewise, i.e. 1 / 2 / 2 / 4 taps for phases (0,0) / (0,1) / (1,0) / (1,1) -- 9 in all, nothing multiplied by
+  // zero.  The K loop runs over (phase, 16-channel chunk); a halo tile is one phase plane, staged like CONV_S1.
+  constexpr int NTAPS = (MODE == CONV_T2 || MODE == CONV_S2) ? 4 : 9;  // weight taps resident in LDS
   constexpr int NG = PAIRN ? 2 : 1;            // channel groups per block
   constexpr int NA = PAIRN ? 1 : 2;            // pixel tiles per block
   constexpr int NBLK = 32 * NT;                // channels per group
@@ -204,6 +208,10 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
         if (MODE == CONV_S1 || MODE == CONV_T2) {
           y = trow0 + hy - 1, x = hx - 1;
           ok = (y >= 0) && (y < H) && (x >= 0) && (x < W);
+        } else if (MODE == CONV_S2) {
+          const int pi = trow0 + hy - 1, pj = hx - 1;  // phase-plane coordinates; phase (0,0) pixel = (2 pi, 2 pj)
+          ok = (pi >= 0) && (pi < H) && (pj >= 0) && (pj < W);
+          y = 2 * pi, x = 2 * pj;
         } else {
           const int yu = trow0 + hy - 1, xu = hx - 1;
           ok = (yu >= 0) && (yu < H) && (xu >= 0) && (xu < W);
@@ -232,7 +240,8 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
   const int ab_slot = (NA == 2 && g.spt == 1) ? (tid >> 3) * 4 : (tid >> 3);  // table index ga * 4 + s
 
   const int cin = a.C0 + a.C1;
-  const int nch_main = cin / KC;
+  const int nch_in = cin / KC;                                   // 16-channel chunks of the input
+  const int nch_main = (MODE == CONV_S2) ? 4 * nch_in : nch_in;  // K chunks (x 4 phases for stride 2)
   const int nch_skip = (a.res_mode == 2) ? (a.R0 + a.R1) / KC : 0;
   const int ntot = nch_main + nch_skip;
   const char* wpk3 = reinterpret_cast<const char*>(a.wpk3);
@@ -245,8 +254,10 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
     const bool skip = ch >= nch_main;
     const float* src;
     int cs, cc, c;
+    int ph = 0;  // CONV_S2: phase of the chunk
     if (!skip) {
-      c = ch * KC;
+      if (MODE == CONV_S2) ph = ch / nch_in;
+      c = (ch - ph * nch_in) * KC;
       if (c < a.C0) src = a.in0, cs = a.C0, cc = c;
       else src = a.in1, cs = a.C1, cc = c - a.C0;
     } else {
@@ -261,15 +272,24 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
 #pragma unroll
     for (int j = 0; j < MAXIT; ++j) ra[j] = *(const bx_gf32x4*)(src + (((size_t)poff[j] * cs + cc) & 0x3FF) + q4 * 4);  // experiment
 #else
+    {
+      const unsigned pshift = (MODE == CONV_S2) ? (unsigned)((ph >> 1) * a.Win + (ph & 1)) : 0u;  // phase pixel offset
 #pragma unroll
-    for (int j = 0; j < MAXIT; ++j)
-      ra[j] = *(const bx_gf32x4*)(src + (size_t)(__umul24((unsigned)poff[j], (unsigned)cs) + (unsigned)(cc + q4 * 4)));
+      for (int j = 0; j < MAXIT; ++j)
+        ra[j] = *(const bx_gf32x4*)(src + (size_t)(__umul24((unsigned)poff[j] + pshift, (unsigned)cs) + (unsigned)(cc + q4 * 4)));
+    }
 #endif
     // packed weights: the chunk's LDS image ([tap][NG groups][NBLK channels] records of 96 B, halves
     // pre-swapped) is contiguous in global memory (launch_pack_conv_bx3 with nb = NBLK * NG)
-    const int nbit = skip ? NBLK * NG * 6 : NBIG * NG;
+    int nbit = skip ? NBLK * NG * 6 : NBIG * NG;
     const char* w0 = skip ? wskip3 + ((size_t)(blockIdx.y * nch_skip + (ch - nch_main))) * (NBLK * NG * 96)
                           : wpk3 + ((size_t)((pc * gridDim.y + blockIdx.y) * nch_main + ch) * NTAPS) * (NBLK * NG * 96);
+    if (MODE == CONV_S2) {
+      // packed [channel block][phase][chunk][taps of the phase][nb]: 0 / 1 / 3 / 5 taps precede phases 0..3
+      const int ntp = ((ph >> 1) + 1) * ((ph & 1) + 1), tbefore = (ph == 0) ? 0 : (ph == 1 ? 1 : (ph == 2 ? 3 : 5));
+      nbit = ntp * NBLK * NG * 6;
+      w0 = wpk3 + ((size_t)blockIdx.y * 9 * nch_in + (size_t)tbefore * nch_in + (size_t)(ch - ph * nch_in) * ntp) * (NBLK * NG * 96);
+    }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int it = tid + 512 * j;
@@ -287,7 +307,8 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
 
   auto commit = [&](int ch) {
     const bool skip = ch >= nch_main;
-    const int chc = ch * KC;  // first channel of the chunk in the concatenated input
+    const int phc = (MODE == CONV_S2 && !skip) ? ch / nch_in : 0;
+    const int chc = (ch - phc * nch_in) * KC;  // first channel of the chunk in the concatenated input
     const bool gnk = a.gn_stats0 != nullptr;
     const bool xform = !skip && (a.ab != nullptr || gnk);
     PROF_T(tc0);
@@ -325,7 +346,8 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
     }
     PROF_T(tc2);
     PROF_ADD(4, tc1, tc2);
-    const int nbit = skip ? NBLK * NG * 6 : NBIG * NG;
+    int nbit = skip ? NBLK * NG * 6 : NBIG * NG;
+    if (MODE == CONV_S2) nbit = ((phc >> 1) + 1) * ((phc & 1) + 1) * NBLK * NG * 6;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int it = tid + 512 * j;
@@ -406,12 +428,20 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
     if (ch + 1 < ntot) issue(ch + 1);
     PROF_T(ti1);
     PROF_ADD(1, ti0, ti1);
-    const int tap_lo = skip ? 4 : 0, tap_hi = skip ? 5 : NTAPS;
+    const int phm = (MODE == CONV_S2) ? ch / nch_in : 0, pa = phm >> 1, pb = phm & 1;
+    const int tap_lo = skip ? 4 : 0, tap_hi = skip ? 5 : (MODE == CONV_S2 ? (pa + 1) * (pb + 1) : NTAPS);
 #pragma unroll 1
     for (int tap = tap_lo; tap < tap_hi; ++tap) {
       int ky, kx;
-      if (MODE == CONV_T2) ky = py + (tap >> 1), kx = px + (tap & 1);
-      else ky = tap / 3, kx = tap - 3 * ky;
+      if (MODE == CONV_T2) {
+        ky = py + (tap >> 1), kx = px + (tap & 1);
+      } else if (MODE == CONV_S2) {
+        // halo rows are plane rows r - 1 (ky = 0) and r (ky = 1): phase a = 0 uses r only; a = 1 uses r - 1 then r
+        const int ty = pb ? (tap >> 1) : tap, tx = pb ? (tap & 1) : 0;
+        ky = pa ? ty : 1, kx = pb ? tx : 1;
+      } else {
+        ky = tap / 3, kx = tap - 3 * ky;
+      }
       const int toff = ky * WR + kx;
       const int boff = (skip ? 0 : tap) * (NBLK * NG * RW);
       bf16x8 af[2][3], bf[NT][3];
@@ -575,6 +605,41 @@ __global__ void pack_deconv_bx3_kernel(const float* w, unsigned short* out, int 
   }
 }
 
+// stride-2 3x3 conv: [Cout][Cin][3][3] -> [Cout/nb][4 phases][Cin/16][taps of the phase][nb][3][16] bf16.
+// Phase (a, b), tap (ty, tx): kernel row = a ? 2 * ty : 1 (plane row r - 1 is input row 2r - 1 = kernel row 0,
+// plane row r of phase a = 1 is input row 2r + 1 = kernel row 2; phase a = 0 is input row 2r = kernel row 1).
+__global__ void pack_conv_bx3_s2_kernel(const float* w, unsigned short* out, int Cout, int Cin, int nb) {
+  const int nch = Cin / 16;
+  const size_t total = (size_t)Cout * Cin * 9;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int kk = i % 16;
+    size_t r = i / 16;                      // record index
+    const size_t per_blk = (size_t)9 * nch * nb;
+    const int blk = (int)(r / per_blk);
+    size_t q = r - (size_t)blk * per_blk;   // record within the channel block
+    int ph = 0, tbefore = 0;
+    for (int p = 0; p < 4; ++p) {
+      const int ntp = ((p >> 1) + 1) * ((p & 1) + 1);
+      if (q < (size_t)ntp * nch * nb) { ph = p; break; }
+      q -= (size_t)ntp * nch * nb;
+      tbefore += ntp;
+    }
+    const int pa = ph >> 1, pb = ph & 1, ntp = (pa + 1) * (pb + 1);
+    const int ch = (int)(q / ((size_t)ntp * nb));
+    const int rem = (int)(q - (size_t)ch * ntp * nb);
+    const int tap = rem / nb, n = rem - tap * nb;
+    const int ty = pb ? (tap >> 1) : tap, tx = pb ? (tap & 1) : 0;
+    const int kyo = pa ? 2 * ty : 1, kxo = pb ? 2 * tx : 1;
+    const int co = blk * nb + n, ci = ch * 16 + kk;
+    unsigned short h, m, l;
+    split1(w[((size_t)co * Cin + ci) * 9 + kyo * 3 + kxo], h, m, l);
+    const int kq = kk ^ ((((tap * nb + n) >> 3) & 1) << 3);
+    unsigned short* rec = out + r * 48;
+    rec[kq] = h, rec[16 + kq] = m, rec[32 + kq] = l;
+    (void)tbefore;
+  }
+}
+
 // channels one workgroup covers: 128 when Cout % 128 == 0 (two 64-channel groups), else 64 or 32
 int bx3_block_channels(int Cout) { return Cout % 128 == 0 ? 128 : (Cout % 64 == 0 ? 64 : 32); }
 
@@ -582,10 +647,18 @@ void launch_pack_conv_bx3(const float* w, void* out, int Cout, int Cin, int taps
   hipLaunchKernelGGL(pack_conv_bx3_kernel, dim3(256), dim3(256), 0, s, w, (unsigned short*)out, Cout, Cin, taps,
                      bx3_block_channels(Cout));
 }
+void launch_pack_conv_bx3_s2(const float* w, void* out, int Cout, int Cin, hipStream_t s) {
+  hipLaunchKernelGGL(pack_conv_bx3_s2_kernel, dim3(256), dim3(256), 0, s, w, (unsigned short*)out, Cout, Cin,
+                     bx3_block_channels(Cout));
+}
 void launch_pack_deconv_bx3(const float* w, void* out, int Cin, int Cout, hipStream_t s) {
   hipLaunchKernelGGL(pack_deconv_bx3_kernel, dim3(256), dim3(256), 0, s, w, (unsigned short*)out, Cin, Cout,
                      bx3_block_channels(Cout));
 }
+
+// halo of one tile in this kernel: (th + 2) x (W + 2) plane pixels per sample in every mode (ConvArgs::halo_px is
+// the fp32 kernel's, which differs for stride 2)
+static int bx3_halo(const ConvArgs& a) { return a.g.spt * (a.g.th + 2) * (a.g.W + 2); }
 
 static bool bx3_pairn(const ConvArgs& a) {
   const int nt = (a.Cout % 64 == 0) ? 2 : 1;
@@ -593,20 +666,22 @@ static bool bx3_pairn(const ConvArgs& a) {
 }
 static size_t bx3w_lds_bytes(const ConvArgs& a, int mode) {
   const int nt = (a.Cout % 64 == 0) ? 2 : 1;
-  const int ntaps = mode == CONV_T2 ? 4 : 9;
+  const int ntaps = (mode == CONV_T2 || mode == CONV_S2) ? 4 : 9;
   const bool pn = bx3_pairn(a);
-  size_t bytes = (size_t)((pn ? 1 : 2) * a.halo_px + ntaps * 32 * nt * (pn ? 2 : 1)) * RW + (256 + 128) * sizeof(float);
+  size_t bytes = (size_t)((pn ? 1 : 2) * bx3_halo(a) + ntaps * 32 * nt * (pn ? 2 : 1)) * RW + (256 + 128) * sizeof(float);
   if (a.gn_stats0) bytes += (size_t)(pn ? 1 : 2) * a.g.spt * (a.C0 + a.C1) * 2 * sizeof(float);  // scale/shift table
   return bytes;
 }
 bool conv_bx3_supported(const ConvArgs& a, int mode) {
-  if (mode == CONV_S2 || !a.wpk3 || a.ep_scale) return false;  // (the BatchNorm+SiLU epilogue of the ratio nets stays on conv_mfma.hip)
+  if (!a.wpk3 || a.ep_scale) return false;  // (the BatchNorm+SiLU epilogue of the ratio nets stays on conv_mfma.hip)
   if (a.res_mode == 2 && !a.wskip3) return false;
   // 24-bit pixel indices and 32-bit element offsets inside the kernel (B = 8192 rows of 32x32x256 still fit)
   const size_t px_in = (size_t)a.B * a.Hin * a.Win, px_out = (size_t)a.B * a.g.HW * (mode == CONV_T2 ? 4 : 1);
   const size_t cmax = (size_t)(a.C0 > a.C1 ? a.C0 : a.C1) > (size_t)a.Cout ? (size_t)(a.C0 > a.C1 ? a.C0 : a.C1) : (size_t)a.Cout;
   if (px_in >= (1u << 24) || px_out >= (1u << 24) || (px_in > px_out ? px_in : px_out) * cmax >= (1ull << 32)) return false;
-  return a.halo_px <= 448 && bx3w_lds_bytes(a, mode) <= 160 * 1024;
+  if (mode == CONV_S2 && getenv("RGFM_S2_F32")) return false;  // A/B switch: stride-2 convs on the fp32 kernel
+  if (mode == CONV_S2 && (a.Hin != 2 * a.g.H || a.Win != 2 * a.g.W || a.C1 != 0 || a.res_mode != 0)) return false;
+  return bx3_halo(a) <= 448 && bx3w_lds_bytes(a, mode) <= 160 * 1024;
 }
 
 bool conv_bx3_gn_supported(const ConvArgs& a, int mode) {
@@ -628,11 +703,14 @@ int conv_bx3_init() {
   RAISEW(1, CONV_S1, false); RAISEW(1, CONV_UP2, false); RAISEW(1, CONV_T2, false);
   RAISEW(2, CONV_S1, false); RAISEW(2, CONV_UP2, false); RAISEW(2, CONV_T2, false);
   RAISEW(2, CONV_S1, true); RAISEW(2, CONV_UP2, true); RAISEW(2, CONV_T2, true);
+  RAISEW(1, CONV_S2, false); RAISEW(2, CONV_S2, false); RAISEW(2, CONV_S2, true);
 #undef RAISEW
   return rc;
 }
 
-void launch_conv_bx3(const ConvArgs& a, int mode, hipStream_t s) {
+void launch_conv_bx3(const ConvArgs& a_in, int mode, hipStream_t s) {
+  ConvArgs a = a_in;
+  a.halo_px = bx3_halo(a_in);
   const int nt = (a.Cout % 64 == 0) ? 2 : 1;
   {
     const int tiles = geom_num_tiles(a.g, a.B);
@@ -643,14 +721,17 @@ void launch_conv_bx3(const ConvArgs& a, int mode, hipStream_t s) {
     if (pn) {
       if (mode == CONV_S1) LAUNCHW(2, CONV_S1, true);
       else if (mode == CONV_UP2) LAUNCHW(2, CONV_UP2, true);
+      else if (mode == CONV_S2) LAUNCHW(2, CONV_S2, true);
       else LAUNCHW(2, CONV_T2, true);
     } else if (nt == 2) {
       if (mode == CONV_S1) LAUNCHW(2, CONV_S1, false);
       else if (mode == CONV_UP2) LAUNCHW(2, CONV_UP2, false);
+      else if (mode == CONV_S2) LAUNCHW(2, CONV_S2, false);
       else LAUNCHW(2, CONV_T2, false);
     } else {
       if (mode == CONV_S1) LAUNCHW(1, CONV_S1, false);
       else if (mode == CONV_UP2) LAUNCHW(1, CONV_UP2, false);
+      else if (mode == CONV_S2) LAUNCHW(1, CONV_S2, false);
       else LAUNCHW(1, CONV_T2, false);
     }
 #undef LAUNCHW

@@ -661,7 +661,10 @@ extern "C" int rgfm_unet_create(const rgfm_unet_desc* desc, const float* params_
       pack_one(h, r.c2, s);
       if (r.has_skip) pack_one(h, r.sk, s);
     }
-  for (const ConvW& w : h->down) pack_one(h, w, s);
+  for (const ConvW& w : h->down) {  // stride-2 convs: phase-ordered split-bf16 weights
+    pack_one(h, w, s);
+    launch_pack_conv_bx3_s2(h->params + w.w_raw, h->packed3 + w.w_bx3, w.cout, w.cin, s);
+  }
   for (const ConvW& w : h->up) pack_one(h, w, s);
   // frequency table exp(-ln(1e4) * i / half) in fp32, as torch evaluates it (unet_flexible.py:28-31)
   const int half = h->mc / 2;
@@ -1508,7 +1511,11 @@ extern "C" int rgfm_fmnet_create(const rgfm_fmnet_desc* desc, const float* param
   if (hipMalloc(&h->packed3, (h->n_packed3 + 8) * sizeof(unsigned short)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(packed3)");
   if (hipMemcpyAsync(h->params, params_dev, n_floats * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
     return bail(RGFM_EHIP, "hipMemcpyAsync(params)");
-  for (const ConvW& w : h->ec) launch_pack_conv_bx3(h->params + w.w_raw, h->packed3 + w.w_bx3, w.cout, w.cin, 9, s);
+  for (int i = 0; i < 3; ++i) {  // encoder conv2 / conv3 are stride 2 (phase-ordered weights), conv4 stride 1
+    const ConvW& w = h->ec[i];
+    if (i < 2) launch_pack_conv_bx3_s2(h->params + w.w_raw, h->packed3 + w.w_bx3, w.cout, w.cin, s);
+    else launch_pack_conv_bx3(h->params + w.w_raw, h->packed3 + w.w_bx3, w.cout, w.cin, 9, s);
+  }
   launch_pack_conv_bx3(h->params + h->c3.w_raw, h->packed3 + h->c3.w_bx3, 32, 64, 9, s);
   launch_pack_deconv_bx3(h->params + h->d1.w_raw, h->packed3 + h->d1.w_bx3, 256, 128, s);
   launch_pack_deconv_bx3(h->params + h->d2.w_raw, h->packed3 + h->d2.w_bx3, 128, 64, s);

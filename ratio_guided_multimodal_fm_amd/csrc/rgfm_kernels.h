@@ -193,6 +193,7 @@ int conv_bx3_init();
 void launch_conv_bx3(const ConvArgs& a, int mode, hipStream_t s);
 void launch_pack_conv_bx3(const float* w, void* out, int Cout, int Cin, int taps, hipStream_t s);
 void launch_pack_deconv_bx3(const float* w, void* out, int Cin, int Cout, hipStream_t s);
+void launch_pack_conv_bx3_s2(const float* w, void* out, int Cout, int Cin, hipStream_t s);  // weights of a stride-2 3x3 conv
 
 // Winograd F(2x2,3x3) variant (conv_wino.hip) for stride-1 3x3 convs at 8/16/32 resolution, Cout % 64 == 0
 bool conv_wino_supported(const ConvArgs& a, int mode);
