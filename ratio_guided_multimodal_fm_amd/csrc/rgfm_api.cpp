@@ -266,6 +266,7 @@ struct rgfm_unet {
   size_t n_params = 0, n_packed = 0;
   int mc = 0, temb = 0, nlin = 0, temb_total = 0;
   size_t te0w, te0b, te2w, te2b, icw, icb, onw, onb, ocw, ocb;
+  size_t ocw_pk = 0;  // out_conv weights re-laid out for conv_out_kernel (offset into `packed`)
   std::vector<ResW> enc, mid, dec;
   std::vector<ConvW> down, up;
   int final_ch = 0;
@@ -347,10 +348,11 @@ size_t plan_unet(const rgfm_unet_desc& d, rgfm_unet* h) {
   for (int uc : up_ch) up.push_back(conv(uc, uc, 9));
   const size_t onw = c.take(ch), onb = c.take(ch);
   const size_t ocw = c.take((size_t)d.in_channels * ch * 9), ocb = c.take(d.in_channels);
+  const size_t ocw_pk = pk.take((size_t)d.in_channels * ch * 9);
   if (h) {
     h->mc = mc, h->temb = temb;
     h->te0w = te0w, h->te0b = te0b, h->te2w = te2w, h->te2b = te2b;
-    h->icw = icw, h->icb = icb, h->onw = onw, h->onb = onb, h->ocw = ocw, h->ocb = ocb;
+    h->icw = icw, h->icb = icb, h->onw = onw, h->onb = onb, h->ocw = ocw, h->ocb = ocb, h->ocw_pk = ocw_pk;
     h->enc = enc, h->mid = mid, h->dec = dec, h->down = down, h->up = up;
     h->final_ch = ch;
     h->temb_total = temb_off;
@@ -580,7 +582,7 @@ struct UNetRun {
     if (!dry) {
       flush_conv(pend, s);
       ConvOutArgs co{};
-      co.in = cur.data, co.ab = ab, co.w = h->params + h->ocw, co.bias = h->params + h->ocb;
+      co.in = cur.data, co.ab = ab, co.w = h->packed + h->ocw_pk, co.bias = h->params + h->ocb;
       co.v_out = v_out, co.x_state = x_state, co.dt = dt, co.B = B, co.Cin = cur.C;
       co.g = make_geom(cur.S, cur.S);
       co.halo_px = co.g.spt * (co.g.th + 2) * (co.g.W + 2);
@@ -666,6 +668,7 @@ extern "C" int rgfm_unet_create(const rgfm_unet_desc* desc, const float* params_
     launch_pack_conv_bx3_s2(h->params + w.w_raw, h->packed3 + w.w_bx3, w.cout, w.cin, s);
   }
   for (const ConvW& w : h->up) pack_one(h, w, s);
+  launch_pack_conv_out(h->params + h->ocw, h->packed + h->ocw_pk, desc->in_channels, h->final_ch, s);
   // frequency table exp(-ln(1e4) * i / half) in fp32, as torch evaluates it (unet_flexible.py:28-31)
   const int half = h->mc / 2;
   std::vector<float> fr(half);
@@ -1292,7 +1295,7 @@ struct rgfm_fmnet {
   ConvW d1, d2;                      // decoder.deconv1/2 (taps = 16 raw, packed per parity)
   size_t dgw[3], dgb[3];             // decoder.gn1..3
   ConvW c3;                          // decoder.conv3
-  size_t cow = 0, cob = 0;           // decoder.conv_out (reference layout, conv_out kernel)
+  size_t cow = 0, cob = 0, cow_pk = 0;  // decoder.conv_out (raw; re-laid out for conv_out_kernel in `packed`)
 };
 
 namespace {
@@ -1332,6 +1335,7 @@ size_t plan_fmnet(const rgfm_fmnet_desc& d, rgfm_fmnet* h) {
   t.c3 = conv(64, 32, 9);
   t.dgw[2] = c.take(32), t.dgb[2] = c.take(32);
   t.cow = c.take((size_t)d.img_channels * 32 * 9), t.cob = c.take(d.img_channels);
+  t.cow_pk = pk.take((size_t)d.img_channels * 32 * 9);
   if (h) {
     float *pa = h->params, *pp = h->packed, *fr = h->freqs;
     unsigned short* p3p = h->packed3;
@@ -1458,7 +1462,7 @@ struct FmRun {
     if (!dry) {
       flush_conv(pend, s);
       ConvOutArgs co{};
-      co.in = u3.data, co.ab = ab3, co.w = h->params + h->cow, co.bias = h->params + h->cob;
+      co.in = u3.data, co.ab = ab3, co.w = h->packed + h->cow_pk, co.bias = h->params + h->cob;
       co.v_out = v_out, co.x_state = x_state, co.dt = dt, co.B = B, co.Cin = 32;
       co.g = make_geom(FM_S, FM_S);
       co.halo_px = co.g.spt * (co.g.th + 2) * (co.g.W + 2);
@@ -1523,6 +1527,7 @@ extern "C" int rgfm_fmnet_create(const rgfm_fmnet_desc* desc, const float* param
   launch_pack_conv(h->params + h->c3.w_raw, h->packed + h->c3.w_pk, 32, 64, 9, 1, s);
   launch_pack_deconv(h->params + h->d1.w_raw, h->packed + h->d1.w_pk, 256, 128, nt32_of(128), s);
   launch_pack_deconv(h->params + h->d2.w_raw, h->packed + h->d2.w_pk, 128, 64, nt32_of(64), s);
+  launch_pack_conv_out(h->params + h->cow, h->packed + h->cow_pk, desc->img_channels, 32, s);
   launch_permute_cols(h->params + h->fcw, h->packed + h->fc_pk, F, FM_CF, FM_P, s);
   launch_permute_rows(h->params + h->f1w, h->params + h->f1b, h->packed + h->f1w_pk, h->packed + h->f1b_pk, FM_CF, FM_P,
                       F + T, s);

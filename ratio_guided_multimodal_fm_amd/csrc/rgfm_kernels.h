@@ -136,7 +136,7 @@ struct ConvInArgs {  // first conv of a net: NCHW image -> NHWC features
 struct ConvOutArgs {  // out_conv(silu(out_norm(h))) -> NCHW velocity, optional fused Euler
   const float* in;    // NHWC [B][H][W][Cin]
   const float* ab;    // [B][Cin][2]
-  const float* w;     // [CIMG][Cin][3][3] (reference layout)
+  const float* w;     // [Cin/16][9][CIMG][16] (launch_pack_conv_out)
   const float* bias;
   float* v_out;       // NCHW velocity or null
   float* x_state;     // NCHW state for the fused Euler update or null
@@ -203,6 +203,7 @@ void launch_wino_pack(const float* w, float* out, int Cout, int Cin, hipStream_t
 
 void launch_conv_in(const ConvInArgs& a, int cin, hipStream_t s);
 void launch_conv_out(const ConvOutArgs& a, int cimg, hipStream_t s);
+void launch_pack_conv_out(const float* w, float* out, int cimg, int Cin, hipStream_t s);
 void launch_gn_finalize(const GnFinalizeArgs& a, hipStream_t s);
 void launch_time_embed(const TimeEmbedArgs& a, int nt, hipStream_t s);
 void launch_pack_conv(const float* w, float* out, int Cout, int Cin, int taps, int nt32, hipStream_t s);

@@ -186,11 +186,13 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const ConvOutArgs a) {
         const f32x4 t = *reinterpret_cast<const f32x4*>(ap + 4 * j);
         v[4 * j] = t.x, v[4 * j + 1] = t.y, v[4 * j + 2] = t.z, v[4 * j + 3] = t.w;
       }
+      // weights re-laid out as [chunk][tap][co][16] (launch_pack_conv_out): the 16 * CIMG scalars of a tap are
+      // contiguous, so they arrive as wide scalar loads instead of 16 * CIMG strided s_load_dword
+      const float* wt = a.w + ((size_t)(ch * 9 + tap) * CIMG) * KC;
 #pragma unroll
       for (int co = 0; co < CIMG; ++co)
 #pragma unroll
-        for (int kk = 0; kk < KC; ++kk)
-          acc[co] += v[kk] * a.w[((size_t)co * a.Cin + ch * KC + kk) * 9 + tap];
+        for (int kk = 0; kk < KC; ++kk) acc[co] += v[kk] * wt[co * KC + kk];
     }
   }
   if (!valid) return;
@@ -203,6 +205,23 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const ConvOutArgs a) {
     if (a.v_out) a.v_out[idx] = v;
     if (a.x_state) a.x_state[idx] = __fadd_rn(a.x_state[idx], __fmul_rn(v, a.dt));
   }
+}
+
+// out_conv weight [CIMG][Cin][3][3] -> [Cin/16][9][CIMG][16]
+__global__ void pack_conv_out_kernel(const float* w, float* out, int cimg, int Cin) {
+  const int total = cimg * Cin * 9;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int kk = i % 16;
+    int r = i / 16;
+    const int co = r % cimg;
+    r /= cimg;
+    const int tap = r % 9, ch = r / 9;
+    out[i] = w[((size_t)co * Cin + ch * 16 + kk) * 9 + tap];
+  }
+}
+
+void launch_pack_conv_out(const float* w, float* out, int cimg, int Cin, hipStream_t s) {
+  hipLaunchKernelGGL(pack_conv_out_kernel, dim3(16), dim3(256), 0, s, w, out, cimg, Cin);
 }
 
 void launch_conv_out(const ConvOutArgs& a, int cimg, hipStream_t s) {
