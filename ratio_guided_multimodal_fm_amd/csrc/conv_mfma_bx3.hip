@@ -6,10 +6,13 @@
 // < 2^-23 |a*b|, i.e. below the rounding of a single fp32 multiply.  The bf16 pipe runs 16x the
 // fp32-MFMA rate, so six passes still leave ~2.7x of MFMA headroom over v_mfma_f32_32x32x2_f32.
 //
-// Same fusion set, tiling, prefetch structure and epilogue as conv_mfma_pf_kernel (see conv_mfma.hip);
-// differences: LDS records are 3 planes x 16 bf16 (+16 B pad = 112 B, conflict-free for ds_read_b128),
-// the staging path splits the (GroupNorm+SiLU-transformed) activations, weights arrive pre-split from
-// launch_pack_conv_bx3 / launch_pack_deconv_bx3, and one workgroup per CU (115 KB of LDS).
+// Same fusion set, register tile, prefetch structure and epilogue as conv_mfma_pf_kernel (see conv_mfma.hip), plus:
+// stride-2 convs (four input parity phases), the consumer-side GroupNorm (scale/shift derived in the prologue from
+// the producers' partial statistics) and the producer-side finalize (rgfm_device.h).  Differences in the data path:
+// LDS records are 3 planes x 16 bf16 = 96 B, unpadded, halves swapped on odd groups of 8 records (conflict-free
+// ds_read_b128); the staging path splits the (GroupNorm+SiLU-transformed) activations; weights arrive pre-split, as
+// the byte image of the LDS tile, from launch_pack_conv_bx3 / _s2 / launch_pack_deconv_bx3; one 512-thread
+// workgroup per CU (two waves per SIMD, 100-155 KB of LDS).  DESIGN.md section 4 has the measurements.
 #include <stdlib.h>
 
 #include "rgfm_device.h"
@@ -265,20 +268,12 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
       if (c < a.R0) src = a.res0, cs = a.R0, cc = c;
       else src = a.res1, cs = a.R1, cc = c - a.R0;
     }
-#if defined(BX3_EXP_NOA)
-#pragma unroll
-    for (int j = 0; j < MAXIT; ++j) ra[j] = f32x4{1.f, 1.f, 1.f, 1.f};
-#elif defined(BX3_EXP_ASMALL)
-#pragma unroll
-    for (int j = 0; j < MAXIT; ++j) ra[j] = *(const bx_gf32x4*)(src + (((size_t)poff[j] * cs + cc) & 0x3FF) + q4 * 4);  // experiment
-#else
     {
       const unsigned pshift = (MODE == CONV_S2) ? (unsigned)((ph >> 1) * a.Win + (ph & 1)) : 0u;  // phase pixel offset
 #pragma unroll
       for (int j = 0; j < MAXIT; ++j)
         ra[j] = *(const bx_gf32x4*)(src + (size_t)(__umul24((unsigned)poff[j] + pshift, (unsigned)cs) + (unsigned)(cc + q4 * 4)));
     }
-#endif
     // packed weights: the chunk's LDS image ([tap][NG groups][NBLK channels] records of 96 B, halves
     // pre-swapped) is contiguous in global memory (launch_pack_conv_bx3 with nb = NBLK * NG)
     int nbit = skip ? NBLK * NG * 6 : NBIG * NG;
@@ -293,11 +288,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int it = tid + 512 * j;
-#if defined(BX3_EXP_NOB)
-      rb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#else
       rb[j] = *(const bx_gf32x4*)(w0 + (size_t)(it < nbit ? it : 0) * 16);
-#endif
     }
     if (!skip && a.ab && !a.gn_stats0) {
       const size_t o = ab_b >= 0 ? ((size_t)ab_b * cin + c + 2 * (tid & 7)) * 2 : 0;
