@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librgfm_hip.so")
+# RGFM_LIB: another build of the same ABI (A/B measurements of two library versions inside one run)
+LIB_PATH = os.environ.get("RGFM_LIB") or os.path.join(_HERE, "csrc", "librgfm_hip.so")
 ABI_VERSION = 1
 
 _lib = None
