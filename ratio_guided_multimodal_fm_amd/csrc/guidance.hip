@@ -19,77 +19,88 @@ namespace rgfm {
 constexpr int GD = 64;        // D-chunk
 constexpr int GLD = GD + 4;   // LDS row stride (floats): conflict-free b128 rows
 
+// Squared distances, sliced along D: block (bx, by, z) adds up slice z of one modality for a 32 x 32 tile of
+// (row, MC sample) pairs and writes the fp64 partial sum; guid_apply adds the slices (fp64 sums of fp32 chunk
+// partials are exact, so the slicing does not change a bit) -- 4x the workgroups of an unsliced launch at the
+// benchmark shape, where 16 x 8 tiles would leave half of the 256 CUs idle on a kernel that nothing overlaps.
 __global__ __launch_bounds__(256) void guid_logp_kernel(const GuidanceArgs a) {
   __shared__ __attribute__((aligned(16))) float sx[32 * GLD];
   __shared__ __attribute__((aligned(16))) float sm[32 * GLD];
   const int tid = threadIdx.x;
   const int tb = tid >> 4, ti = tid & 15;
   const int bb = blockIdx.x * 32, ib = blockIdx.y * 32;
-  float lsum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-  for (int part = 0; part < 2; ++part) {
-    const float* X = part ? a.y : a.x;
-    const float* M = part ? a.mc_y1 : a.mc_x1;
-    const int D = part ? a.dy : a.dx;
-    // chunk partials in fp32 (64 terms), running total in fp64: the sum is then exact
-    // to fp32 rounding, which matters because l is later scaled by 1/sigma_t^2 (up to ~8e3)
-    double S[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
-    for (int d0 = 0; d0 < D; d0 += GD) {
-      __syncthreads();
-      // 32 rows x 16 float4 for each operand: 512 items each, 2 per thread
-      for (int it = tid; it < 512; it += 256) {
-        const int row = it >> 4, q = it & 15;
-        const int d = d0 + q * 4;
-        f32x4 vx = {0.f, 0.f, 0.f, 0.f}, vm = {0.f, 0.f, 0.f, 0.f};
-        if (d < D) {
-          if (bb + row < a.B) vx = *reinterpret_cast<const f32x4*>(X + (size_t)(bb + row) * D + d);
-          if (ib + row < a.N) {
-            vm = *reinterpret_cast<const f32x4*>(M + (size_t)(ib + row) * D + d);
-            vm.x = __fmul_rn(a.tf, vm.x);  // mu = t * x_1 (rounded, as the reference)
-            vm.y = __fmul_rn(a.tf, vm.y);
-            vm.z = __fmul_rn(a.tf, vm.z);
-            vm.w = __fmul_rn(a.tf, vm.w);
-          }
+  const int z = blockIdx.z;
+  const int part = z >= a.nsx ? 1 : 0;
+  const float* X = part ? a.y : a.x;
+  const float* M = part ? a.mc_y1 : a.mc_x1;
+  const int D = part ? a.dy : a.dx;
+  const int dbeg = (part ? z - a.nsx : z) * a.slice_len;
+  const int dend = dbeg + a.slice_len < D ? dbeg + a.slice_len : D;
+  // chunk partials in fp32 (64 terms), running total in fp64: the sum is then exact
+  // to fp32 rounding, which matters because l is later scaled by 1/sigma_t^2 (up to ~8e3)
+  double S[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+  for (int d0 = dbeg; d0 < dend; d0 += GD) {
+    __syncthreads();
+    // 32 rows x 16 float4 for each operand: 512 items each, 2 per thread
+    for (int it = tid; it < 512; it += 256) {
+      const int row = it >> 4, q = it & 15;
+      const int d = d0 + q * 4;
+      f32x4 vx = {0.f, 0.f, 0.f, 0.f}, vm = {0.f, 0.f, 0.f, 0.f};
+      if (d < dend) {
+        if (bb + row < a.B) vx = *reinterpret_cast<const f32x4*>(X + (size_t)(bb + row) * D + d);
+        if (ib + row < a.N) {
+          vm = *reinterpret_cast<const f32x4*>(M + (size_t)(ib + row) * D + d);
+          vm.x = __fmul_rn(a.tf, vm.x);  // mu = t * x_1 (rounded, as the reference)
+          vm.y = __fmul_rn(a.tf, vm.y);
+          vm.z = __fmul_rn(a.tf, vm.z);
+          vm.w = __fmul_rn(a.tf, vm.w);
         }
-        *reinterpret_cast<f32x4*>(sx + row * GLD + q * 4) = vx;
-        *reinterpret_cast<f32x4*>(sm + row * GLD + q * 4) = vm;
       }
-      __syncthreads();
-      float c[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+      *reinterpret_cast<f32x4*>(sx + row * GLD + q * 4) = vx;
+      *reinterpret_cast<f32x4*>(sm + row * GLD + q * 4) = vm;
+    }
+    __syncthreads();
+    float c[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-      for (int d = 0; d < GD; d += 4) {
-        f32x4 xv[2], mv[2];
-        xv[0] = *reinterpret_cast<const f32x4*>(sx + tb * GLD + d);
-        xv[1] = *reinterpret_cast<const f32x4*>(sx + (tb + 16) * GLD + d);
-        mv[0] = *reinterpret_cast<const f32x4*>(sm + ti * GLD + d);
-        mv[1] = *reinterpret_cast<const f32x4*>(sm + (ti + 16) * GLD + d);
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            float df;
-            df = xv[p].x - mv[q].x, c[p][q] += df * df;
-            df = xv[p].y - mv[q].y, c[p][q] += df * df;
-            df = xv[p].z - mv[q].z, c[p][q] += df * df;
-            df = xv[p].w - mv[q].w, c[p][q] += df * df;
-          }
-      }
+    for (int d = 0; d < GD; d += 4) {
+      f32x4 xv[2], mv[2];
+      xv[0] = *reinterpret_cast<const f32x4*>(sx + tb * GLD + d);
+      xv[1] = *reinterpret_cast<const f32x4*>(sx + (tb + 16) * GLD + d);
+      mv[0] = *reinterpret_cast<const f32x4*>(sm + ti * GLD + d);
+      mv[1] = *reinterpret_cast<const f32x4*>(sm + (ti + 16) * GLD + d);
 #pragma unroll
       for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) S[p][q] += (double)c[p][q];
+        for (int q = 0; q < 2; ++q) {
+          float df;
+          df = xv[p].x - mv[q].x, c[p][q] += df * df;
+          df = xv[p].y - mv[q].y, c[p][q] += df * df;
+          df = xv[p].z - mv[q].z, c[p][q] += df * df;
+          df = xv[p].w - mv[q].w, c[p][q] += df * df;
+        }
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
-      for (int q = 0; q < 2; ++q) lsum[p][q] = __fadd_rn(lsum[p][q], __fmul_rn(-0.5f, (float)S[p][q]) / a.s2);
+      for (int q = 0; q < 2; ++q) S[p][q] += (double)c[p][q];
   }
 #pragma unroll
   for (int p = 0; p < 2; ++p)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int b = bb + tb + 16 * p, i = ib + ti + 16 * q;
-      if (b < a.B && i < a.N) a.logp[(size_t)b * a.N + i] = lsum[p][q];
+      if (b < a.B && i < a.N) a.dist[((size_t)z * a.B + b) * a.N + i] = S[p][q];
     }
+}
+
+// l[b,i] = -0.5 |x_b - t m^x_i|^2 / s2 + -0.5 |y_b - t m^y_i|^2 / s2 from the sliced sums (each modality's
+// term rounded to fp32 on its own, then added: the reference's two-statement form, :141-143)
+__device__ __forceinline__ float logp_of(const GuidanceArgs& a, int b, int i) {
+  double sx = 0.0, sy = 0.0;
+  for (int z = 0; z < a.nsx; ++z) sx += a.dist[((size_t)z * a.B + b) * a.N + i];
+  for (int z = a.nsx; z < a.nsx + a.nsy; ++z) sy += a.dist[((size_t)z * a.B + b) * a.N + i];
+  const float lx = __fadd_rn(0.f, __fmul_rn(-0.5f, (float)sx) / a.s2);
+  return __fadd_rn(lx, __fmul_rn(-0.5f, (float)sy) / a.s2);
 }
 
 __device__ __forceinline__ float wave_sum_g(float v) {
@@ -112,13 +123,16 @@ __global__ __launch_bounds__(256) void guid_apply_kernel(const GuidanceArgs a, i
   {  // importance weights of row b0 + wave (sample_mnist_svhn.py:146-156)
     const int b = b0 + wave;
     if (b < a.B) {
-      const float* lp = a.logp + (size_t)b * N;
       float mx = -INFINITY;
-      for (int i = lane; i < N; i += 64) mx = fmaxf(mx, lp[i]);
+      for (int i = lane; i < N; i += 64) {
+        const float l = logp_of(a, b, i);
+        sw[wave * N + i] = l;
+        mx = fmaxf(mx, l);
+      }
       mx = wave_max_g(mx);
       float ps = 0.f, zs = 0.f;
       for (int i = lane; i < N; i += 64) {
-        const float p = expf(lp[i] - mx);
+        const float p = expf(sw[wave * N + i] - mx);
         sw[wave * N + i] = p;
         ps += p;
         zs += __fmul_rn(a.mc_ratios[i], p);
@@ -199,7 +213,7 @@ __global__ __launch_bounds__(256) void guid_apply_kernel(const GuidanceArgs a, i
 }
 
 void launch_guidance(const GuidanceArgs& a, hipStream_t s) {
-  dim3 g1((a.B + 31) / 32, (a.N + 31) / 32);
+  dim3 g1((a.B + 31) / 32, (a.N + 31) / 32, a.nsx + a.nsy);
   hipLaunchKernelGGL(guid_logp_kernel, g1, dim3(256), 0, s, a);
   const size_t lds = (size_t)4 * a.N * sizeof(float);
   hipLaunchKernelGGL(guid_apply_kernel, dim3((a.B + 3) / 4, (a.dx + 1023) / 1024), dim3(256), lds, s, a, 0);

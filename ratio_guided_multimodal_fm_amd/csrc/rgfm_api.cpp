@@ -840,9 +840,13 @@ extern "C" int rgfm_sample_single(rgfm_unet* h, float* x_inout, int batch, int n
   return RGFM_OK;
 }
 
+static size_t guid_scratch_bytes(int batch, int n_mc) {  // sliced fp64 distances, RGFM_GUID_SLICES slices at most
+  return (((size_t)RGFM_GUID_SLICES * batch * (n_mc > 0 ? n_mc : 1) * sizeof(double)) + 255) & ~(size_t)255;
+}
+
 extern "C" int rgfm_guidance_workspace_bytes(int batch, int n_mc, size_t* bytes) {
   if (!bytes || batch < 1 || n_mc < 1) return fail(RGFM_EINVAL, "bad argument");
-  *bytes = (((size_t)batch * n_mc * sizeof(float)) + 255) & ~(size_t)255;
+  *bytes = guid_scratch_bytes(batch, n_mc);
   return RGFM_OK;
 }
 
@@ -861,7 +865,10 @@ int guidance_launch(const float* x, const float* y, float* vx, float* vy, const 
   a.B = B, a.N = N, a.dx = dx, a.dy = dy;
   a.tf = (float)t, a.s2 = (float)(sigma_t * sigma_t), a.cden = (float)(1.0 - t + eps);
   a.g1 = (float)(1.0 - gamma), a.g2 = (float)gamma;
-  a.logp = logp, a.weights_out = weights_out, a.x_state = xs, a.y_state = ys, a.dt = dt;
+  a.dist = reinterpret_cast<double*>(logp), a.weights_out = weights_out, a.x_state = xs, a.y_state = ys, a.dt = dt;
+  a.slice_len = 1024;  // 1024-element slices unless that needs more than RGFM_GUID_SLICES of them
+  while ((dx + a.slice_len - 1) / a.slice_len + (dy + a.slice_len - 1) / a.slice_len > RGFM_GUID_SLICES) a.slice_len *= 2;
+  a.nsx = (dx + a.slice_len - 1) / a.slice_len, a.nsy = (dy + a.slice_len - 1) / a.slice_len;
   ProfScope p(RGFM_KCLASS_OTHER, 0, s);
   launch_guidance(a, s);
   return RGFM_OK;
@@ -949,7 +956,7 @@ extern "C" int rgfm_sample_pair_workspace_bytes(const rgfm_unet* hx, const rgfm_
   const size_t dy = (size_t)hy->d.in_channels * hy->d.img_size * hy->d.img_size;
   size_t total = table_bytes(hx, 4096) + table_bytes(hy, 4096) + ex + ey + 2 * counter_bytes(batch);  // the two nets run concurrently
   total += ((batch * dx * 4 + 255) & ~(size_t)255) + ((batch * dy * 4 + 255) & ~(size_t)255);
-  total += (((size_t)batch * (n_mc > 0 ? n_mc : 1) * 4) + 255) & ~(size_t)255;
+  total += guid_scratch_bytes(batch, n_mc);
   *bytes = total;
   return RGFM_OK;
 }
@@ -977,7 +984,7 @@ extern "C" int rgfm_sample_pair(rgfm_unet* hx, rgfm_unet* hy, float* x_inout, fl
   float* ty = b.f((size_t)4096 * hy->temb_total);
   float* vx = b.f((size_t)batch * dx);
   float* vy = b.f((size_t)batch * dy);
-  float* logp = b.f((size_t)batch * (n_mc > 0 ? n_mc : 1));
+  float* logp = b.f(guid_scratch_bytes(batch, n_mc) / sizeof(float));
   unsigned* cnt_x = reinterpret_cast<unsigned*>(b.f(batch));
   unsigned* cnt_y = reinterpret_cast<unsigned*>(b.f(batch));
   HIP_TRY(hipMemsetAsync(cnt_x, 0, (size_t)batch * sizeof(unsigned), s));
@@ -1605,7 +1612,7 @@ extern "C" int rgfm_fmnet_sample_pair_workspace_bytes(const rgfm_fmnet* hx, cons
   const size_t d = (size_t)FM_S * FM_S;
   size_t total = fm_eval_bytes(const_cast<rgfm_fmnet*>(hx), batch) + fm_eval_bytes(const_cast<rgfm_fmnet*>(hy), batch);
   total += 2 * ((batch * d * 4 + 255) & ~(size_t)255) + 2 * counter_bytes(batch);
-  total += (((size_t)batch * (n_mc > 0 ? n_mc : 1) * 4) + 255) & ~(size_t)255;
+  total += guid_scratch_bytes(batch, n_mc);
   *bytes = total;
   return RGFM_OK;
 }
@@ -1629,7 +1636,7 @@ extern "C" int rgfm_fmnet_sample_pair(rgfm_fmnet* hx, rgfm_fmnet* hy, float* x_i
   b.base = (char*)ws, b.cap = ws_bytes, b.dry = false;
   float* vx = b.f((size_t)batch * d);
   float* vy = b.f((size_t)batch * d);
-  float* logp = b.f((size_t)batch * (n_mc > 0 ? n_mc : 1));
+  float* logp = b.f(guid_scratch_bytes(batch, n_mc) / sizeof(float));
   unsigned* cnt_x = reinterpret_cast<unsigned*>(b.f(batch));
   unsigned* cnt_y = reinterpret_cast<unsigned*>(b.f(batch));
   HIP_TRY(hipMemsetAsync(cnt_x, 0, (size_t)batch * sizeof(unsigned), s));

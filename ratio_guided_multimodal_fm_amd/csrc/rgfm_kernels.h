@@ -244,12 +244,14 @@ struct GuidanceArgs {
   const float* mc_ratios;
   int B, N, dx, dy;
   float tf, s2, cden, g1, g2;
-  float* logp;         // [B][N] scratch
+  double* dist;        // [nsx + nsy][B][N] scratch: sliced squared distances (guid_logp -> guid_apply)
+  int slice_len, nsx, nsy;  // D-slices per modality (<= RGFM_GUID_SLICES in all)
   float* weights_out;  // optional [B][N]
   float* x_state;      // optional fused Euler: x_state += dt * blended
   float* y_state;
   float dt;
 };
+constexpr int RGFM_GUID_SLICES = 8;
 void launch_guidance(const GuidanceArgs& a, hipStream_t s);
 void launch_euler(float* x, const float* v, size_t n, float dt, hipStream_t s);
 
