@@ -15,6 +15,8 @@
 // workgroup per CU (two waves per SIMD, 100-155 KB of LDS).  DESIGN.md section 4 has the measurements.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "rgfm_device.h"
 
 namespace rgfm {
@@ -466,68 +468,75 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
   int lane_e = lane;
   asm volatile("" : "+v"(lane_e));
   const int l31 = lane_e & 31, h = lane_e >> 5;
-  unsigned vmask[2] = {0u, 0u};
+  // Two instantiations of the same epilogue: FULL (every pixel of this wave's 64-pixel segment is valid -- all
+  // waves of all interior tiles) has no per-element predicates, which are a third of its instructions.
+  auto epilogue = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    unsigned vmask[2] = {0u, 0u};
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int pl = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
-      const int p = 64 * seg + pl;
-      const bool valid = (g.spt == 1) ? (sample_ok && p < nvalid) : (sample_ok && pl < HW);
-      if (valid) vmask[mt] |= 1u << r;
-      unsigned pix = (unsigned)pix0 + (unsigned)((g.spt == 1) ? p : pl);
-      if (MODE == CONV_T2) {
-        const int pp = (g.spt == 1) ? row0 * W + p : pl;
-        const int rr = (int)(__umul24((unsigned)pp, mW) >> 16), xx = pp - rr * W;
-        pix = (unsigned)((bw * (2 * H) + 2 * rr + py) * (2 * W) + 2 * xx + px);
+      for (int r = 0; r < 16; ++r) {
+        const int pl = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int p = 64 * seg + pl;
+        const bool valid = FULL || ((g.spt == 1) ? (sample_ok && p < nvalid) : (sample_ok && pl < HW));
+        if (!FULL && valid) vmask[mt] |= 1u << r;
+        unsigned pix = (unsigned)pix0 + (unsigned)((g.spt == 1) ? p : pl);
+        if (MODE == CONV_T2) {
+          const int pp = (g.spt == 1) ? row0 * W + p : pl;
+          const int rr = (int)(__umul24((unsigned)pp, mW) >> 16), xx = pp - rr * W;
+          pix = (unsigned)((bw * (2 * H) + 2 * rr + py) * (2 * W) + 2 * xx + px);
+        }
+        float* op = a.out + (size_t)(__umul24(pix, (unsigned)a.Cout) + (unsigned)(n0 + l31));
+        if (valid) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) op[nt * 32] = acc[mt][nt][r];
+        }
       }
-      float* op = a.out + (size_t)(__umul24(pix, (unsigned)a.Cout) + (unsigned)(n0 + l31));
-      if (valid) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) op[nt * 32] = acc[mt][nt][r];
+    if (a.stats_out) {
+      int nw;
+      if (FULL) {
+        nw = 64;
+      } else if (g.spt == 1) {
+        nw = nvalid - 64 * seg;
+        nw = nw < 0 ? 0 : (nw > 64 ? 64 : nw);
+        if (!sample_ok) nw = 0;
+      } else {
+        nw = sample_ok ? HW : 0;
       }
-    }
-  if (a.stats_out) {
-    int nw;
-    if (g.spt == 1) {
-      nw = nvalid - 64 * seg;
-      nw = nw < 0 ? 0 : (nw > 64 ? 64 : nw);
-      if (!sample_ok) nw = 0;
-    } else {
-      nw = sample_ok ? HW : 0;
-    }
-    const int nparts = (MODE == CONV_T2) ? 4 * g.nparts : g.nparts;
-    const int part = ((g.spt == 1) ? (my_tile - b0 * g.tps) * 4 + seg : 0) + pc * g.nparts;
+      const int nparts = (MODE == CONV_T2) ? 4 * g.nparts : g.nparts;
+      const int part = ((g.spt == 1) ? (my_tile - b0 * g.tps) * 4 + seg : 0) + pc * g.nparts;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      float s = 0.f;
+      for (int nt = 0; nt < NT; ++nt) {
+        float s = 0.f;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (vmask[mt] & (1u << r)) s += acc[mt][nt][r];
-      s += __shfl_xor(s, 32);
-      const float mean = nw > 0 ? s / (float)nw : 0.f;
-      float m2 = 0.f;
+          for (int r = 0; r < 16; ++r)
+            if (FULL || (vmask[mt] & (1u << r))) s += acc[mt][nt][r];
+        s += __shfl_xor(s, 32);
+        const float mean = nw > 0 ? s / (float)nw : 0.f;
+        float m2 = 0.f;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (vmask[mt] & (1u << r)) {
-            const float d = acc[mt][nt][r] - mean;
-            m2 += d * d;
-          }
-      m2 += __shfl_xor(m2, 32);
-      if (h == 0 && sample_ok) {
-        const int c = n0 + nt * 32 + l31;
-        float2 st;
-        st.x = mean;
-        st.y = m2;
-        store_stats(a, a.stats_out + (((size_t)bw * nparts + part) * a.Cout + c) * 2, mean, m2);
+          for (int r = 0; r < 16; ++r)
+            if (FULL || (vmask[mt] & (1u << r))) {
+              const float d = acc[mt][nt][r] - mean;
+              m2 += d * d;
+            }
+        m2 += __shfl_xor(m2, 32);
+        if (h == 0 && sample_ok) {
+          const int c = n0 + nt * 32 + l31;
+          store_stats(a, a.stats_out + (((size_t)bw * nparts + part) * a.Cout + c) * 2, mean, m2);
+        }
       }
+      if (a.fin_ab && sample_ok) fin_arrive(a, bw, lane_e, nparts, MODE == CONV_T2);
     }
-    if (a.fin_ab && sample_ok) fin_arrive(a, bw, lane_e, nparts, MODE == CONV_T2);
-  }
+  };
+  const bool full_seg = sample_ok && ((g.spt == 1) ? (nvalid - 64 * seg >= 64) : (HW == 64));  // wave-uniform
+  if (full_seg) epilogue(std::true_type{});
+  else epilogue(std::false_type{});
 #ifdef RGFM_BX3_PROF
   PROF_T(te1);
   PROF_ADD(6, te0, te1);
