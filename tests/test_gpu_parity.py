@@ -330,6 +330,32 @@ def test_full_size_properties(dev):
     assert maxdiff(ya[rows].cpu().numpy(), oy) < TOL_SAMPLER
 
 
+def test_full_size_arithmetic_modes_agree(dev, monkeypatch):
+    """BASELINE-size batch: the default path (split-bf16 conv, consumer-side GroupNorm) and the exact-fp32 MFMA
+    path with table GroupNorm must agree on ALL 512 rows of a guided integration (the oracle can only afford a
+    few rows at this size), and the full-size result is reproducible run to run (no atomics in the data path)."""
+    fm, fs, rr = make_module("mnist32", dev), make_module("svhn", dev), make_module("ratio_ms", dev)
+    B, N, S, nsteps = 512, 256, 100, 6
+    x0, y0, mx0, my0 = (t.to(dev) for t in paired_noise(10, B, N, (1, 32, 32), (3, 32, 32)))
+    res = {}
+    for tag, env in (("default", {}), ("again", {}), ("fp32", {"RGFM_CONV": "f32", "RGFM_GN": "table"})):
+        for k in ("RGFM_CONV", "RGFM_GN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        mx1, my1 = mx0.clone(), my0.clone()
+        _engine.sample_single(fm, mx1, S, 0, nsteps)
+        _engine.sample_single(fs, my1, S, 0, nsteps)
+        r = rr._engine.eval(mx1, my1, "ratio")
+        xa, ya = x0.clone(), y0.clone()
+        _engine.sample_pair(fm, fs, xa, ya, mx1, my1, r, S, 1.0, 0, nsteps)
+        res[tag] = (xa.cpu().numpy(), ya.cpu().numpy(), r.cpu().numpy())
+    assert np.array_equal(res["default"][0], res["again"][0]) and np.array_equal(res["default"][1], res["again"][1])
+    assert maxdiff(res["default"][2], res["fp32"][2]) < TOL_EVAL * max(1.0, float(np.abs(res["fp32"][2]).max()))
+    assert maxdiff(res["default"][0], res["fp32"][0]) < TOL_SAMPLER
+    assert maxdiff(res["default"][1], res["fp32"][1]) < TOL_SAMPLER
+
+
 @pytest.mark.parametrize("env", [{"RGFM_CONV": "f32"}, {"RGFM_CONV": "f32", "RGFM_WINO": "1"}, {"RGFM_CONV": "v3"},
                                  {"RGFM_GN": "table"}, {"RGFM_GN": "table", "RGFM_FUSE_FIN": "0"},
                                  {"RGFM_CONV": "f32", "RGFM_FUSE_FIN": "0"}])
