@@ -160,6 +160,30 @@ def gen_unet_layers():
         save(f"unet_layers_{tag}", **out)
 
 
+GENERIC_UNETS = {  # FlexibleUNet shapes outside the three presets: odd tile counts, 4 levels, tiny maps, 3 blocks
+    "g24": dict(in_channels=3, img_size=24, model_channels=32, channel_mult=(1, 2, 4), num_res_blocks=1),
+    "g16": dict(in_channels=1, img_size=16, model_channels=64, channel_mult=(1, 1, 2, 2), num_res_blocks=3),
+    "g40": dict(in_channels=3, img_size=40, model_channels=32, channel_mult=(2, 2), num_res_blocks=2),
+}
+
+
+def gen_unet_generic():
+    from src.models.unet_flexible import FlexibleUNet as RefFlex
+    out = {}
+    for i, (tag, kw) in enumerate(GENERIC_UNETS.items()):
+        ref = RefFlex(**kw)
+        mine = ours.FlexibleUNet(**kw)
+        assert list(ref.state_dict().keys()) == list(mine.state_dict().keys())
+        ref.load_state_dict(synth_state_dict(mine, 70 + i))
+        ref.eval()
+        x = torch.randn(5, kw["in_channels"], kw["img_size"], kw["img_size"], generator=torch.Generator().manual_seed(300 + i))
+        t = torch.tensor([0.0, 0.2, 0.5, 0.8, 0.99])
+        with torch.no_grad():
+            out[f"{tag}_out"] = n(ref(x, t))
+        out[f"{tag}_x_fp"] = n(x.reshape(-1)[:8])
+    save("unet_generic", **out)
+
+
 def gen_fp64():
     """The reference nets evaluated in float64 (same weights and inputs, cast up): the yardstick for
     the arithmetic error of the fp32-MFMA and the split-bf16 (bx3) conv paths."""
@@ -388,8 +412,8 @@ def gen_fm_original():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["embedding", "unet_layers", "ratio", "guidance", "samplers", "coherence", "fm_original", "coherence28", "fp64"]
+    which = sys.argv[1:] or ["embedding", "unet_layers", "ratio", "guidance", "samplers", "coherence", "fm_original", "coherence28", "fp64", "unet_generic"]
     for w in which:
         {"embedding": gen_embedding, "unet_layers": gen_unet_layers, "ratio": gen_ratio,
          "guidance": gen_guidance, "samplers": gen_samplers, "coherence": gen_coherence,
-         "fm_original": gen_fm_original, "coherence28": gen_coherence28, "fp64": gen_fp64}[w]()
+         "fm_original": gen_fm_original, "coherence28": gen_coherence28, "fp64": gen_fp64, "unet_generic": gen_unet_generic}[w]()

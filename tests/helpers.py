@@ -79,3 +79,20 @@ def oracle_fm_pair(blob_x, blob_y, ratio_blob, noise, guided, gamma, steps):
             vx, vy = O.guidance_apply(x, y, vx, vy, mx, my, r, t, gamma)[:2]
         x, y = x + vx * dt, y + vy * dt
     return x, y
+
+
+# must match tests/golden/make_golden.py
+GENERIC_UNETS = {
+    "g24": dict(in_channels=3, img_size=24, model_channels=32, channel_mult=(1, 2, 4), num_res_blocks=1),
+    "g16": dict(in_channels=1, img_size=16, model_channels=64, channel_mult=(1, 1, 2, 2), num_res_blocks=3),
+    "g40": dict(in_channels=3, img_size=40, model_channels=32, channel_mult=(2, 2), num_res_blocks=2),
+}
+
+
+def make_generic_unet(tag, device=None):
+    i = list(GENERIC_UNETS).index(tag)
+    m = load_synth(M.FlexibleUNet(**GENERIC_UNETS[tag]), 70 + i).eval()
+    x = torch.randn(5, GENERIC_UNETS[tag]["in_channels"], GENERIC_UNETS[tag]["img_size"], GENERIC_UNETS[tag]["img_size"],
+                    generator=torch.Generator().manual_seed(300 + i))
+    t = torch.tensor([0.0, 0.2, 0.5, 0.8, 0.99])
+    return (m.to(device) if device is not None else m), x, t

@@ -73,6 +73,25 @@ def test_unet_ragged_batches(dev, tag, B):
     assert np.isfinite(out).all()
 
 
+@pytest.mark.parametrize("tag", ["g24", "g16", "g40"])
+@pytest.mark.parametrize("env", [{}, {"RGFM_CONV": "f32"}, {"RGFM_GN": "table"}])
+def test_generic_flexible_unets(dev, tag, env, monkeypatch):
+    """FlexibleUNet shapes outside the presets -- 24x24 (three tiles per sample: tile pairs straddle samples, 12
+    statistics parts), 16x16 with four levels down to 2x2 maps and three blocks per level, 40x40 (tiles of 6 rows,
+    7 per sample) -- against the reference's output and, layer by layer, the oracle."""
+    from helpers import make_generic_unet
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    g = golden("unet_generic")
+    m, x, t = make_generic_unet(tag, dev)
+    out, acts = m._engine.forward_trace(x.to(dev), t.to(dev))
+    ro, racts = O.unet_forward(O.desc_of(m), O.blob_of(m), x.numpy(), t.numpy(), trace=True)
+    for i, (a, r) in enumerate(zip(acts, racts)):
+        d = maxdiff(a.cpu().numpy(), r)
+        assert d < TOL_EVAL * max(1.0, float(np.abs(r).max())), (tag, i, d)
+    assert maxdiff(out.cpu().numpy(), g[f"{tag}_out"]) < TOL_EVAL
+
+
 def test_unet_empty_batch_and_errors(dev):
     m = make_module("mnist32", dev)
     out = m(torch.empty(0, 1, 32, 32, device=dev), torch.empty(0, device=dev))
