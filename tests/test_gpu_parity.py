@@ -349,6 +349,40 @@ def test_full_size_properties(dev):
     assert maxdiff(ya[rows].cpu().numpy(), oy) < TOL_SAMPLER
 
 
+def test_full_size_config2_28x28(dev, monkeypatch):
+    """BASELINE configs[1] at full size (MNIST 28x28 pair, batch 256, N_mc 128, gamma 0.5), a few of the 100 steps:
+    oracle on three rows, row independence, and agreement of the two conv arithmetic modes on every row."""
+    fx, fy, rr = make_module("unet28", dev), make_module("unet28_y", dev), make_module("ratio28", dev)
+    B, N, S, nsteps = 256, 128, 100, 4
+    x0, y0, mx0, my0 = (t.to(dev) for t in paired_noise(11, B, N, (1, 28, 28), (1, 28, 28)))
+    res = {}
+    for tag, env in (("default", {}), ("fp32", {"RGFM_CONV": "f32", "RGFM_GN": "table"})):
+        for k in ("RGFM_CONV", "RGFM_GN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        mx1, my1 = mx0.clone(), my0.clone()
+        _engine.sample_single(fx, mx1, S, 0, nsteps)
+        _engine.sample_single(fy, my1, S, 0, nsteps)
+        r = rr._engine.eval(mx1, my1, "ratio")
+        xa, ya = x0.clone(), y0.clone()
+        _engine.sample_pair(fx, fy, xa, ya, mx1, my1, r, S, 0.5, 0, nsteps)
+        res[tag] = (xa, ya, mx1, my1, r)
+    xa, ya, mx1, my1, r = res["default"]
+    assert maxdiff(xa.cpu().numpy(), res["fp32"][0].cpu().numpy()) < TOL_SAMPLER
+    assert maxdiff(ya.cpu().numpy(), res["fp32"][1].cpu().numpy()) < TOL_SAMPLER
+    xb, yb = x0[40:47].clone(), y0[40:47].clone()  # 7 rows on their own: ragged tiles, same MC set
+    _engine.sample_pair(fx, fy, xb, yb, mx1, my1, r, S, 0.5, 0, nsteps)
+    assert maxdiff(xa[40:47].cpu().numpy(), xb.cpu().numpy()) < 1e-5
+    dx, bx = oracle_net("unet28")
+    dy, by = oracle_net("unet28_y")
+    rows = [0, 100, 255]
+    ox, oy = O.sample_pair(dx, bx, dy, by, x0[rows].cpu().numpy(), y0[rows].cpu().numpy(), mx1.cpu().numpy(),
+                           my1.cpu().numpy(), r.cpu().numpy(), S, 0.5, 0, nsteps)
+    assert maxdiff(xa[rows].cpu().numpy(), ox) < TOL_SAMPLER
+    assert maxdiff(ya[rows].cpu().numpy(), oy) < TOL_SAMPLER
+
+
 def test_full_size_arithmetic_modes_agree(dev, monkeypatch):
     """BASELINE-size batch: the default path (split-bf16 conv, consumer-side GroupNorm) and the exact-fp32 MFMA
     path with table GroupNorm must agree on ALL 512 rows of a guided integration (the oracle can only afford a
