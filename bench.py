@@ -148,7 +148,8 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    conv_mode = os.environ.get("RGFM_CONV", "bx3")
+    conv_mode_env = os.environ.get("RGFM_CONV")
+    conv_mode = conv_mode_env or "bx3"
     alt = None
     if rank == 0 and world == 1 and timers and conv_mode == "bx3" and not args.no_alt_mode:
         # the same call once more with the exact-fp32 MFMA conv (the switch is read per launch)
@@ -166,6 +167,29 @@ def main():
         ach_a = a_fl / (a_ms * 1e-3) / 1e12
         alt = {"conv": "v_mfma_f32_32x32x2_f32 (RGFM_CONV=f32)", "value": B / alt_elapsed, "unit": "paired images/sec",
                "achieved": ach_a, "peak": PEAK_FP32_MFMA_TFLOPS, "frac": ach_a / PEAK_FP32_MFMA_TFLOPS, "calls": 1}
+
+    arith = None
+    gpath = os.path.join(ROOT, "tests", "golden", "fp64_eval.npz")
+    if rank == 0 and world == 1 and os.path.exists(gpath):
+        # error of one SVHN-net evaluation against the reference evaluated in float64 (committed golden vector,
+        # tests/golden/make_golden.py) in both conv arithmetic modes: the split-bf16 default is fp32-class
+        import numpy as np
+        from ratio_guided_multimodal_fm_amd.synth import load_synth as _ls
+        g = np.load(gpath)
+        net = _ls(M.FlowMatchingUNetSVHN(), 14).eval().to(dev)  # the weights the golden vector was made with
+        xg = torch.randn(4, 3, 32, 32, generator=torch.Generator().manual_seed(91)).to(dev)
+        tg = torch.tensor([0.05, 0.37, 0.71, 0.99], device=dev)
+        errs = {}
+        for mode in ("bx3", "f32"):
+            os.environ["RGFM_CONV"] = mode
+            errs[mode] = float(np.abs(net(xg, tg).cpu().numpy().astype(np.float64) - g["svhn_f64"]).max())
+        if conv_mode_env is None:
+            os.environ.pop("RGFM_CONV", None)
+        else:
+            os.environ["RGFM_CONV"] = conv_mode_env
+        arith = {"what": "max |error| of one SVHN U-Net evaluation (B=4) against the reference run in float64",
+                 "split_bf16_default": errs["bx3"], "exact_fp32_mfma": errs["f32"],
+                 "reference_own_fp32": float(g["svhn_ref32_err"])}
 
     if rank == 0:
         assert out[0] is not None and out[0].shape[0] == B and torch.isfinite(out[0]).all()
@@ -224,6 +248,8 @@ def main():
             }
             if alt is not None:
                 line["roofline"]["exact_fp32_mode"] = alt
+            if arith is not None:
+                line["roofline"]["arithmetic_check"] = arith
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
