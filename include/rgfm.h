@@ -13,17 +13,24 @@
  *     the library owns only what *_create allocates and frees it in *_destroy;
  *   - image tensors are NCHW fp32, exactly as the reference passes them;
  *   - `stream` is a hipStream_t (PyTorch: torch.cuda.current_stream().cuda_stream);
- *     all work is enqueued on it, no hidden synchronisation, no allocation
- *     inside forward/sample calls (graph-capturable);
+ *     all work is enqueued on it; forward/sample calls neither synchronise nor
+ *     allocate nor create streams/events (per-device resources are created by the
+ *     first *_create on that device; rgfm_profile_reserve pre-creates the bench
+ *     timers' events) and read the RGFM_* environment switches once on entry;
  *   - return value: 0 on success, a negative RGFM_E* code otherwise; nothing is
  *     thrown across the ABI; rgfm_last_error() returns text for the calling
  *     thread's last failure;
  *   - one host thread per handle; distinct handles are independent;
- *   - arithmetic: fp32 tensors, fp32 accumulation.  The 3x3 / transposed convolutions form
- *     each fp32 product from an exact three-way bf16 split of both operands on the bf16
- *     matrix cores (six products, fp32 accumulate; error against float64 equal to the
- *     fp32 matrix-core path).  Environment variable RGFM_CONV=f32
- *     (read per launch) selects v_mfma_f32_32x32x2_f32 for every convolution instead.
+ *   - arithmetic: fp32 tensors, fp32 accumulation.  By default the 3x3 / transposed
+ *     convolutions form each fp32 product from a two-way fp16 split of both (power-of-two
+ *     scaled) operands on the f16 matrix cores: three products, fp32 accumulate, per-product
+ *     error <= 3 * 2^-24 relative, measured error against float64 equal to the fp32
+ *     matrix-core path.  That path needs |activation| < 2048 and
+ *     finite weights with max|w| in [2^-40, 2^40] per conv; convs outside the weight range
+ *     are routed to the bf16 path at create time, and an activation outside the range raises
+ *     a device flag (rgfm_range_flag_read) on which the caller repeats the call with
+ *     RGFM_CONV=bx3.  RGFM_CONV=bx3: exact three-way bf16 split, six products, fp32 range.
+ *     RGFM_CONV=f32: v_mfma_f32_32x32x2_f32 for every convolution.
  */
 #ifndef RGFM_H_
 #define RGFM_H_
@@ -35,7 +42,7 @@
 extern "C" {
 #endif
 
-#define RGFM_ABI_VERSION 1
+#define RGFM_ABI_VERSION 2
 
 #define RGFM_OK 0
 #define RGFM_EINVAL (-1)    /* bad argument / unsupported shape          */
@@ -224,6 +231,15 @@ int rgfm_profile_reset(void);
  *   sum_ms   = plain sum of the launch durations (== busy_ms when nothing overlaps);
  *   launches, flops = launch count and algorithmic FLOPs (2*MAC). */
 int rgfm_profile_read(int kclass, double* busy_ms, double* sum_ms, int64_t* launches, double* flops);
+
+/* Pre-creates the hipEvents of `launches` timed launches, so that none is created inside a timed region. */
+int rgfm_profile_reserve(int64_t launches);
+
+/* Range flag of the default fp16 conv path (see "arithmetic" above): waits for `stream`, then
+ * *flagged = 1 if any convolution launched on the current device since the last reset staged an
+ * activation outside the fp16 range -- the outputs of those calls must be recomputed with
+ * RGFM_CONV=bx3 (the Python host does this automatically).  reset != 0 clears the flag. */
+int rgfm_range_flag_read(int* flagged, int reset, rgfm_stream_t stream);
 
 int rgfm_abi_version(void);
 const char* rgfm_last_error(void);

@@ -42,11 +42,76 @@ class _Workspace:
 
     def __init__(self):
         self.buf = None
+        self.streams = set()
 
     def get(self, nbytes, device):
+        cur = torch.cuda.current_stream(device)
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            old = self.buf
             self.buf = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+            if old is not None:
+                # work already enqueued on other streams may still use the old buffer: keep the
+                # caching allocator from handing its memory out before those streams get there
+                for st in self.streams:
+                    old.record_stream(st)
+            self.streams = set()
+        self.streams.add(cur)
         return self.buf
+
+
+def engine_property(factory):
+    """Class attribute `_engine = engine_property(factory)`: the module's engine, built on first use.
+
+    The engine is a per-module cache (device handle, packed weights, workspace) kept out of
+    state_dict, deepcopy and pickling: a copied / unpickled module simply builds its own.
+    """
+    def get(module):
+        e = module.__dict__.get("_engine_obj")
+        if e is None or e._module() is not module:
+            e = factory(module)
+            module.__dict__["_engine_obj"] = e
+        return e
+    return property(get)
+
+
+# ---- range guard of the default fp16 conv path -------------------------------------------------
+# conv_mfma_hx2.hip needs |activation| < 2048; outside that it raises a device flag instead of
+# returning wrong numbers silently.  Every public compute entry point below runs under
+# _range_guarded: if the flag is up after the call, the in-place state is restored and the call is
+# repeated with RGFM_CONV=bx3 (split-bf16 convs, fp32 range).  RGFM_RANGE_CHECK=0 disables the
+# check (and its end-of-call synchronisation), e.g. for stream capture.
+
+def _hx2_active():
+    return os.environ.get("RGFM_CONV", "hx2") == "hx2" and os.environ.get("RGFM_RANGE_CHECK", "1") != "0"
+
+
+range_fallbacks = 0  # number of calls repeated on the bf16 path (tests read it)
+
+
+def _range_guarded(device, state, fn):
+    """fn() with the fp16-range check; `state` = tensors fn updates in place."""
+    global range_fallbacks
+    if not _hx2_active():
+        return fn()
+    saved = [t.clone() for t in state]
+    out = fn()
+    flag = ctypes.c_int()
+    with torch.cuda.device(device):
+        _lib.check(_lib.lib().rgfm_range_flag_read(ctypes.byref(flag), 1, _stream(device)))
+    if flag.value:
+        range_fallbacks += 1
+        for t, t0 in zip(state, saved):
+            t.copy_(t0)
+        prev = os.environ.get("RGFM_CONV")
+        os.environ["RGFM_CONV"] = "bx3"
+        try:
+            out = fn()
+        finally:
+            if prev is None:
+                del os.environ["RGFM_CONV"]
+            else:
+                os.environ["RGFM_CONV"] = prev
+    return out
 
 
 class _EngineBase:
@@ -57,7 +122,7 @@ class _EngineBase:
         self._blob = None
         self._ws = _Workspace()
 
-    # engines are per-module caches: never copied or pickled with the module
+    # engines are per-module caches: never copied or pickled with the module (engine_property rebuilds them)
     def __deepcopy__(self, memo):
         return None
 
@@ -148,12 +213,15 @@ class _VelocityEngine(_EngineBase):
         if B == 0:
             return out
         dev = x.device
-        with torch.cuda.device(dev):
-            h = self.handle(dev)
-            ws, nb = self.workspace(f"{self.PREFIX}_workspace_bytes", B, dev)
-            _lib.check(self._fn("forward")(h, _ptr(x), _ptr(t), t.numel(), _ptr(out), B, _ptr(ws), nb,
-                                           _stream(dev)))
-        return out
+
+        def run():
+            with torch.cuda.device(dev):
+                h = self.handle(dev)
+                ws, nb = self.workspace(f"{self.PREFIX}_workspace_bytes", B, dev)
+                _lib.check(self._fn("forward")(h, _ptr(x), _ptr(t), t.numel(), _ptr(out), B, _ptr(ws), nb,
+                                               _stream(dev)))
+            return out
+        return _range_guarded(dev, [], run)
 
 
 class FmNetEngine(_VelocityEngine):
@@ -290,6 +358,12 @@ _sampler_ws = _Workspace()
 
 def sample_single(model, x, num_steps, step_begin=0, step_end=None):
     """In-place unguided Euler integration of `x` (rgfm_sample_single)."""
+    if x.is_cuda and x.shape[0]:
+        return _range_guarded(x.device, [x], lambda: _sample_single(model, x, num_steps, step_begin, step_end))
+    return _sample_single(model, x, num_steps, step_begin, step_end)
+
+
+def _sample_single(model, x, num_steps, step_begin=0, step_end=None):
     eng = model._engine
     eng._check_eval(model)
     _require_hip(x)
@@ -318,20 +392,27 @@ def sample_two_streams(fm_x, x, fm_y, y, num_steps):
     forks from / joins back into the current stream, so callers keep stream-ordered semantics.
     """
     dev = x.device
-    if os.environ.get("RGFM_OVERLAP", "1") == "0":  # A/B switch, same as the library's
-        sample_single(fm_x, x, num_steps)
-        sample_single(fm_y, y, num_steps)
+
+    def run():
+        # one module passed for both modalities (legal in the reference) has ONE engine workspace:
+        # its two integrations must not run concurrently
+        if os.environ.get("RGFM_OVERLAP", "1") == "0" or fm_x._engine is fm_y._engine:
+            _sample_single(fm_x, x, num_steps)
+            _sample_single(fm_y, y, num_steps)
+            return x, y
+        cur = torch.cuda.current_stream(dev)
+        side = _side_streams.get(dev)
+        if side is None:
+            side = _side_streams[dev] = torch.cuda.Stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            _sample_single(fm_y, y, num_steps)
+        _sample_single(fm_x, x, num_steps)
+        cur.wait_stream(side)
         return x, y
-    cur = torch.cuda.current_stream(dev)
-    side = _side_streams.get(dev)
-    if side is None:
-        side = _side_streams[dev] = torch.cuda.Stream(dev)
-    side.wait_stream(cur)
-    with torch.cuda.stream(side):
-        sample_single(fm_y, y, num_steps)
-    sample_single(fm_x, x, num_steps)
-    cur.wait_stream(side)
-    return x, y
+    if x.is_cuda and y.is_cuda:
+        return _range_guarded(dev, [x, y], run)
+    return run()
 
 
 def sample_pair(fm_x, fm_y, x, y, mc_x1, mc_y1, mc_ratios, num_steps, gamma, step_begin=0,
@@ -355,17 +436,20 @@ def sample_pair(fm_x, fm_y, x, y, mc_x1, mc_y1, mc_ratios, num_steps, gamma, ste
     if n_mc:
         mc_x1, mc_y1, mc_ratios = mc_x1.contiguous(), mc_y1.contiguous(), mc_ratios.contiguous()
     L = _lib.lib()
-    with torch.cuda.device(dev):
-        hx, hy = fm_x._engine.handle(dev), fm_y._engine.handle(dev)
-        nb = ctypes.c_size_t()
-        _lib.check(getattr(L, ex.PAIR_WS)(hx, hy, B, n_mc, ctypes.byref(nb)))
-        ws = _sampler_ws.get(nb.value, dev)
-        _lib.check(getattr(L, ex.PAIR)(hx, hy, _ptr(x), _ptr(y), _ptr(mc_x1 if n_mc else None),
-                                      _ptr(mc_y1 if n_mc else None),
-                                      _ptr(mc_ratios if n_mc else None), n_mc, B, int(num_steps),
-                                      float(gamma), int(step_begin), int(step_end), _ptr(ws),
-                                      nb.value, _stream(dev)))
-    return x, y
+
+    def run():
+        with torch.cuda.device(dev):
+            hx, hy = fm_x._engine.handle(dev), fm_y._engine.handle(dev)
+            nb = ctypes.c_size_t()
+            _lib.check(getattr(L, ex.PAIR_WS)(hx, hy, B, n_mc, ctypes.byref(nb)))
+            ws = _sampler_ws.get(nb.value, dev)
+            _lib.check(getattr(L, ex.PAIR)(hx, hy, _ptr(x), _ptr(y), _ptr(mc_x1 if n_mc else None),
+                                          _ptr(mc_y1 if n_mc else None),
+                                          _ptr(mc_ratios if n_mc else None), n_mc, B, int(num_steps),
+                                          float(gamma), int(step_begin), int(step_end), _ptr(ws),
+                                          nb.value, _stream(dev)))
+        return x, y
+    return _range_guarded(dev, [x, y], run)
 
 
 def guidance_apply(x, y, vx, vy, mc_x1, mc_y1, mc_ratios, t, gamma, want_weights=False):
@@ -386,8 +470,10 @@ def guidance_apply(x, y, vx, vy, mc_x1, mc_y1, mc_ratios, t, gamma, want_weights
     return w
 
 
-def profile(enable=None, reset=False):
+def profile(enable=None, reset=False, reserve=None):
     L = _lib.lib()
+    if reserve is not None:
+        _lib.check(L.rgfm_profile_reserve(int(reserve)))
     if enable is not None:
         _lib.check(L.rgfm_profile_enable(1 if enable else 0))
     if reset:

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RGFM_LIB: another build of the same ABI (A/B measurements of two library versions inside one run)
 LIB_PATH = os.environ.get("RGFM_LIB") or os.path.join(_HERE, "csrc", "librgfm_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -76,6 +76,8 @@ SIGNATURES = {
     "rgfm_profile_enable": (c_int, [c_int]),
     "rgfm_profile_reset": (c_int, []),
     "rgfm_profile_read": (c_int, [c_int, P(c_double), P(c_double), P(c_int64), P(c_double)]),
+    "rgfm_profile_reserve": (c_int, [c_int64]),
+    "rgfm_range_flag_read": (c_int, [P(c_int), c_int, c_void_p]),
     "rgfm_abi_version": (c_int, []),
     "rgfm_last_error": (ctypes.c_char_p, []),
 }

@@ -144,6 +144,19 @@ extern "C" int rgfm_profile_read(int kclass, double* busy_ms, double* sum_ms, in
   return RGFM_OK;
 }
 
+extern "C" int rgfm_profile_reserve(int64_t launches) {
+  if (launches < 0) return fail(RGFM_EINVAL, "negative launch count");
+  const size_t want = (size_t)launches * 2;
+  while (g_prof.ev.size() < want) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    g_prof.ev.push_back(e);
+  }
+  g_prof.cls.resize(g_prof.ev.size() / 2);
+  if (!g_prof.base) HIP_TRY(hipEventCreate(&g_prof.base));
+  return RGFM_OK;
+}
+
 // ------------------------------------------------------------------ small helpers
 namespace {
 
@@ -185,8 +198,9 @@ struct ConvW {  // one packed conv
   size_t w_raw = 0, b = 0;  // offsets into the params blob
   size_t w_pk = 0;          // offset into the packed buffer
   size_t w_bx3 = 0;         // offset (bf16 elements) into the 3-plane bf16 buffer of conv_mfma_bx3.hip
-  size_t w_wino = 0;        // offset into the Winograd-transformed buffer (3x3, Cout % 64 == 0 only)
-  bool has_wino = false;
+  size_t w_hx2 = 0;         // offset (fp16 elements) into the 2-plane fp16 buffer of conv_mfma_hx2.hip
+  int hq = 0;               // index of the conv's scale record {q, 1/q, s_w, eligible} in the handle's hq array
+  bool hx_ok = false;       // weights inside the fp16 path's range (set after packing)
   int cin = 0, cout = 0, taps = 9;
 };
 
@@ -208,57 +222,109 @@ bool on_gfx950() {
   return strncmp(p.gcnArchName, "gfx950", 6) == 0;
 }
 
-bool g_conv_init = false;
-int g_num_cus = 256;
-// RGFM_CONV=v3 routes supported convs through the persistent one-block-per-CU kernel of
-// conv_mfma_v3.hip (A/B switch, read per launch; the default is conv_mfma.hip -- see DESIGN.md 4)
-bool use_v3() {
+// Run-time switches, read from the environment ONCE per API call (refresh_modes), never on the launch path:
+//   RGFM_CONV = hx2 (default: conv_mfma_hx2.hip, fp32 operands as two scaled fp16 planes, three f16-MFMA products
+//               per fp32 product) | bx3 (conv_mfma_bx3.hip: three exact bf16 planes, six products; fp32 range)
+//               | f32 (conv_mfma.hip: v_mfma_f32_32x32x2_f32 everywhere);
+//   RGFM_OVERLAP=0   both velocity nets of a step on the caller's stream;
+//   RGFM_FUSE_FIN=0  separate gn_finalize launches instead of the producer-side finalize;
+//   RGFM_GN=table    every GroupNorm finalized into a scale/shift array instead of the consumer-side prologue.
+enum { CONV_ARITH_HX2 = 0, CONV_ARITH_BX3 = 1, CONV_ARITH_F32 = 2 };
+struct Modes {
+  int conv = CONV_ARITH_HX2;
+  bool overlap = true, fuse_fin = true, gn_consumer = true;
+};
+Modes g_modes;
+void refresh_modes() {
+  Modes m;
   const char* e = getenv("RGFM_CONV");
-  return e && strcmp(e, "v3") == 0;
+  if (e && strcmp(e, "bx3") == 0) m.conv = CONV_ARITH_BX3;
+  else if (e && strcmp(e, "f32") == 0) m.conv = CONV_ARITH_F32;
+  e = getenv("RGFM_OVERLAP");
+  m.overlap = !(e && e[0] == '0');
+  e = getenv("RGFM_FUSE_FIN");
+  m.fuse_fin = !(e && e[0] == '0');
+  e = getenv("RGFM_GN");
+  m.gn_consumer = !(e && strcmp(e, "table") == 0);
+  g_modes = m;
 }
-// Conv arithmetic (read per launch).  Default: conv_mfma_bx3.hip -- fp32 operands as three exact bf16
-// planes, six bf16-MFMA products per fp32 product, fp32 accumulate (same error against float64 as
-// the fp32 MFMA, tests/test_gpu_parity.py::test_arithmetic_error_against_float64).
-// RGFM_CONV=f32 forces v_mfma_f32_32x32x2_f32 (conv_mfma.hip) everywhere.
-bool use_bx3() {
-  const char* e = getenv("RGFM_CONV");
-  return !e || strcmp(e, "bx3") == 0;
+
+// Per-device state, created by the first rgfm_*_create on that device (never inside forward / sample calls):
+// raised dynamic-LDS limits (a per-device function attribute), the side stream + fork/join events of the paired
+// sampler, and the range-flag word of conv_mfma_hx2.hip.
+constexpr int MAX_DEVICES = 16;
+struct DevState {
+  bool init = false;
+  int num_cus = 256;
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  unsigned* range_flag = nullptr;
+};
+DevState g_dev[MAX_DEVICES];
+
+DevState* cur_dev() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return nullptr;
+  return g_dev[dev].init ? &g_dev[dev] : nullptr;
 }
+
 int ensure_init() {
   if (!on_gfx950()) return fail(RGFM_ENODEVICE, "librgfm_hip needs a gfx950 (MI355X) device; none is current");
-  if (!g_conv_init) {
-    if (conv_mfma_init() != 0 || conv_v3_init() != 0 || conv_wino_init() != 0 || conv_bx3_init() != 0)
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= MAX_DEVICES) return fail(RGFM_EINVAL, "device ordinal %d out of range (max %d)", dev, MAX_DEVICES - 1);
+  DevState& d = g_dev[dev];
+  if (!d.init) {
+    if (conv_mfma_init() != 0 || conv_bx3_init() != 0 || conv_hx2_init() != 0)
       return fail(RGFM_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-    int dev = 0;
     hipDeviceProp_t p;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) g_num_cus = p.multiProcessorCount;
-    g_conv_init = true;
+    if (hipGetDeviceProperties(&p, dev) == hipSuccess) d.num_cus = p.multiProcessorCount;
+    HIP_TRY(hipStreamCreateWithFlags(&d.side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&d.fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&d.join, hipEventDisableTiming));
+    HIP_TRY(hipMalloc(&d.range_flag, 256));
+    HIP_TRY(hipMemset(d.range_flag, 0, 256));
+    d.init = true;
   }
   return RGFM_OK;
 }
 
-// RGFM_WINO=1 routes eligible stride-1 3x3 convs through the Winograd F(2x2,3x3) kernel (read per launch)
-bool use_wino() {
-  const char* e = getenv("RGFM_WINO");
-  return e && e[0] == '1';
-}
-
-void launch_conv(const ConvArgs& c, int mode, const float* wino, hipStream_t s) {
-  if (wino && use_wino() && conv_wino_supported(c, mode)) launch_conv_wino(c, mode, wino, s);
-  else if (use_bx3() && conv_bx3_supported(c, mode)) launch_conv_bx3(c, mode, s);
-  else if (use_v3() && conv_v3_supported(c, mode)) launch_conv_v3(c, mode, g_num_cus, s);
+void launch_conv(const ConvArgs& c, int mode, hipStream_t s) {
+  if (g_modes.conv == CONV_ARITH_HX2 && conv_hx2_supported(c, mode)) launch_conv_hx2(c, mode, s);
+  else if (g_modes.conv != CONV_ARITH_F32 && conv_bx3_supported(c, mode)) launch_conv_bx3(c, mode, s);
   else launch_conv_mfma(c, mode, s);
 }
 
 }  // namespace
+
+// ------------------------------------------------------------------ fp16-path range flag
+// conv_mfma_hx2.hip ORs 1 into the device's flag word when it stages an activation with |S_A a| >= 32768 (fp16
+// would overflow): the results of every call since the last reset are then unusable and the caller repeats them
+// with RGFM_CONV=bx3 (fp32 range).  Synchronises `stream`.
+extern "C" int rgfm_range_flag_read(int* flagged, int reset, rgfm_stream_t stream) {
+  if (!flagged) return fail(RGFM_EINVAL, "null output");
+  DevState* ds = cur_dev();
+  *flagged = 0;
+  if (!ds) return RGFM_OK;  // nothing has run on this device
+  hipStream_t s = (hipStream_t)stream;
+  unsigned v = 0;
+  HIP_TRY(hipMemcpyAsync(&v, ds->range_flag, sizeof(v), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  *flagged = v ? 1 : 0;
+  if (reset && v) HIP_TRY(hipMemsetAsync(ds->range_flag, 0, sizeof(v), s));
+  return RGFM_OK;
+}
 
 // ================================================================== U-Net
 struct rgfm_unet {
   rgfm_unet_desc d;
   float* params = nullptr;  // device copy of the state_dict-order blob
   float* packed = nullptr;  // packed conv weights
-  float* wino = nullptr;    // Winograd-transformed 3x3 weights
-  size_t n_wino = 0;
+  unsigned short* packedh = nullptr;  // 2-plane scaled fp16 weights (conv_mfma_hx2.hip)
+  size_t n_packedh = 0;
+  float* hq = nullptr;      // [n_hq][4] scale records of packedh
+  int n_hq = 0;
+  unsigned* range_flag = nullptr;  // the device's range-flag word (DevState)
   unsigned short* packed3 = nullptr;  // 3-plane bf16 weights (conv_mfma_bx3.hip)
   size_t n_packed3 = 0;
   float* freqs = nullptr;
@@ -286,7 +352,8 @@ namespace {
 // is identical) and records blob offsets.  Returns the total float count.
 size_t plan_unet(const rgfm_unet_desc& d, rgfm_unet* h) {
   Cursor c;
-  Cursor pk, wk, p3;
+  Cursor pk, p3, ph;
+  int nhq = 0;
   const int mc = d.model_channels, temb = 4 * mc;
   std::vector<ResW> enc, mid, dec;
   std::vector<ConvW> down, up;
@@ -298,8 +365,8 @@ size_t plan_unet(const rgfm_unet_desc& d, rgfm_unet* h) {
     w.b = c.take(cout);
     w.w_pk = pk.take((size_t)cout * cin * taps);
     w.w_bx3 = p3.take((size_t)cout * cin * taps * 3);
-    w.has_wino = taps == 9 && cout % 64 == 0 && cin % 16 == 0;
-    if (w.has_wino) w.w_wino = wk.take((size_t)cout * cin * 16);
+    w.w_hx2 = ph.take((size_t)cout * cin * taps * 2);
+    w.hq = nhq++;
     return w;
   };
   auto res = [&](int cin, int cout) {
@@ -357,7 +424,7 @@ size_t plan_unet(const rgfm_unet_desc& d, rgfm_unet* h) {
     h->final_ch = ch;
     h->temb_total = temb_off;
     h->n_packed = pk.off;
-    h->n_wino = wk.off;
+    h->n_packedh = ph.off, h->n_hq = nhq;
     h->n_packed3 = p3.off;
   }
   return c.off;
@@ -382,10 +449,27 @@ int check_desc(const rgfm_unet_desc* d) {
   return RGFM_OK;
 }
 
-void pack_one(const rgfm_unet* h, const ConvW& w, hipStream_t s) {
+void pack_one(const rgfm_unet* h, const ConvW& w, int mode, hipStream_t s) {
   launch_pack_conv(h->params + w.w_raw, h->packed + w.w_pk, w.cout, w.cin, w.taps, nt32_of(w.cout), s);
-  launch_pack_conv_bx3(h->params + w.w_raw, h->packed3 + w.w_bx3, w.cout, w.cin, w.taps, s);
-  if (w.has_wino) launch_wino_pack(h->params + w.w_raw, h->wino + w.w_wino, w.cout, w.cin, s);
+  if (mode == CONV_S2) launch_pack_conv_bx3_s2(h->params + w.w_raw, h->packed3 + w.w_bx3, w.cout, w.cin, s);
+  else launch_pack_conv_bx3(h->params + w.w_raw, h->packed3 + w.w_bx3, w.cout, w.cin, w.taps, s);
+  launch_pack_conv_hx2(h->params + w.w_raw, h->packedh + w.w_hx2, h->hq + 4 * w.hq, w.cout, w.cin, w.taps, mode, s);
+}
+
+// after the pack launches: which convs may run on the fp16 path (one synchronising copy at create time)
+int read_hx_flags(const float* hq_dev, int n, std::vector<ConvW*>& convs, hipStream_t s) {
+  std::vector<float> host((size_t)n * 4);
+  HIP_TRY(hipMemcpyAsync(host.data(), hq_dev, host.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (ConvW* w : convs) w->hx_ok = host[(size_t)w->hq * 4 + 3] != 0.f;
+  return RGFM_OK;
+}
+
+// fills the fp16-path fields of a conv launch (main conv `w`, optional fused 1x1 skip `sk`)
+void fill_hx2(ConvArgs& c, const unsigned short* packedh, const float* hq, unsigned* flag, const ConvW& w, const ConvW* sk) {
+  if (!w.hx_ok || (sk && !sk->hx_ok)) return;
+  c.wpkh = packedh + w.w_hx2, c.hq = hq + 4 * w.hq, c.range_flag = flag;
+  if (sk) c.wskiph = packedh + sk->w_hx2, c.hq_skip = hq + 4 * sk->hq;
 }
 
 double conv_flops(int B, int HW, int cout, int kprod) { return 2.0 * B * HW * (double)cout * kprod; }
@@ -398,7 +482,6 @@ struct PendingConv {
   bool valid = false;
   ConvArgs c{};
   int mode = 0;
-  const float* wino = nullptr;
   double flops = 0.0;
 };
 
@@ -406,17 +489,13 @@ void flush_conv(PendingConv& p, hipStream_t s) {
   if (!p.valid) return;
   p.valid = false;
   ProfScope ps(RGFM_KCLASS_CONV_MFMA, p.flops, s);
-  launch_conv(p.c, p.mode, p.wino, s);
+  launch_conv(p.c, p.mode, s);
 }
 
 // true when `p` can take the finalize of cat(its output, partner) itself
 bool try_fuse_finalize(PendingConv& p, const float* first_data, const float* stats1, int C1, const float* gamma,
                        const float* beta, float* ab, unsigned* counter) {
-  const char* e = getenv("RGFM_FUSE_FIN");  // A/B switch (read per call)
-  const bool off = e && e[0] == '0';
-  if (off || !p.valid || !counter || p.c.out != first_data || !p.c.stats_out) return false;
-  if (p.wino && use_wino() && conv_wino_supported(p.c, p.mode)) return false;  // (the experimental kernels do not carry it)
-  if (use_v3() && conv_v3_supported(p.c, p.mode)) return false;
+  if (!g_modes.fuse_fin || !p.valid || !counter || p.c.out != first_data || !p.c.stats_out) return false;
   if ((p.c.Cout + C1) % 8 != 0 || p.c.Cout + C1 < 32 || p.c.Cout + C1 > 256) return false;  // <= 4 channels per lane
   if (p.c.g.nparts * (p.mode == CONV_T2 ? 4 : 1) > 16) return false;  // the finalizing wave holds <= 16 partials per channel
   p.c.fin_ab = ab, p.c.fin_counter = counter, p.c.fin_expected = conv_fin_expected(p.c, p.mode);
@@ -424,20 +503,17 @@ bool try_fuse_finalize(PendingConv& p, const float* first_data, const float* sta
   return true;
 }
 
-// RGFM_GN=table: every GroupNorm is finalized into an [B][C][2] scale/shift array (by the producing conv's last
-// wave, or a gn_finalize launch); default: the split-bf16 conv derives it in its own prologue from the partial
-// statistics (ConvArgs::gn_*), the table path remains for the kernels that cannot (conv_out, stride-2, RGFM_CONV=f32).
-bool gn_consumer_side() {
-  const char* e = getenv("RGFM_GN");
-  return !(e && strcmp(e, "table") == 0);
-}
-
-// Tries the consumer-side norm for conv `c`; on failure the gn_* fields are cleared and the caller supplies `ab`.
-bool try_consumer_gn(ConvArgs& c, int mode, const float* wino, const float* stats0, const float* stats1, int nparts0,
-                     const TileGeom& gg, const float* gamma, const float* beta) {
+// Consumer-side GroupNorm (default): the split-operand conv derives the scale/shift in its own prologue from the
+// partial statistics (ConvArgs::gn_*); the table path (RGFM_GN=table) remains for the kernels that cannot
+// (conv_out, RGFM_CONV=f32).  On failure the gn_* fields are cleared and the caller supplies `ab`.
+bool try_consumer_gn(ConvArgs& c, int mode, const float* stats0, const float* stats1, int nparts0, const TileGeom& gg,
+                     const float* gamma, const float* beta) {
   c.gn_stats0 = stats0, c.gn_stats1 = stats1, c.gn_gamma = gamma, c.gn_beta = beta, c.gn_nparts0 = nparts0, c.gn_g = gg;
-  const bool ok = gn_consumer_side() && use_bx3() && !(wino && use_wino() && conv_wino_supported(c, mode)) &&
-                  conv_bx3_gn_supported(c, mode);
+  bool ok = false;
+  if (g_modes.gn_consumer) {
+    if (g_modes.conv == CONV_ARITH_HX2 && conv_hx2_supported(c, mode)) ok = conv_hx2_gn_supported(c, mode);
+    else if (g_modes.conv != CONV_ARITH_F32) ok = conv_bx3_gn_supported(c, mode);
+  }
   if (!ok) c.gn_stats0 = c.gn_stats1 = c.gn_gamma = c.gn_beta = nullptr;
   return ok;
 }
@@ -514,15 +590,15 @@ struct UNetRun {
     c.g = make_geom(So, So);
     c.halo_px = mode == CONV_S2 ? c.g.spt * (2 * c.g.th + 1) * (2 * c.g.W + 1) : c.g.spt * (c.g.th + 2) * (c.g.W + 2);
     const int kprod = 9 * w.cin + (res_mode == 2 ? sk->cin : 0);
-    const float* wino = w.has_wino ? h->wino + w.w_wino : nullptr;
+    fill_hx2(c, h->packedh, h->hq, h->range_flag, w, res_mode == 2 ? sk : nullptr);
     if (norm) {
       const TileGeom gg = make_geom(a.S, a.S);
-      if (!try_consumer_gn(c, mode, wino, a.stats, b ? b->stats : nullptr, gg.nparts, gg, h->params + norm->gamma,
+      if (!try_consumer_gn(c, mode, a.stats, b ? b->stats : nullptr, gg.nparts, gg, h->params + norm->gamma,
                            h->params + norm->beta))
         c.ab = finalize(a, b, norm->gamma, norm->beta, ab_buf);  // (may attach itself to the pending producer)
     }
     flush_conv(pend, s);
-    pend.valid = true, pend.c = c, pend.mode = mode, pend.wino = wino;
+    pend.valid = true, pend.c = c, pend.mode = mode;
     pend.flops = conv_flops(B, So * So, w.cout, kprod);
     return o;
   }
@@ -653,21 +729,22 @@ extern "C" int rgfm_unet_create(const rgfm_unet_desc* desc, const float* params_
   };
   if (hipMalloc(&h->params, n_floats * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(params)");
   if (hipMalloc(&h->packed, (h->n_packed + 4) * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(packed)");
-  if (hipMalloc(&h->wino, (h->n_wino + 4) * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(wino)");
+  if (hipMalloc(&h->packedh, (h->n_packedh + 8) * sizeof(unsigned short)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(packedh)");
+  if (hipMalloc(&h->hq, ((size_t)h->n_hq * 4 + 4) * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(hq)");
+  h->range_flag = cur_dev()->range_flag;
   if (hipMalloc(&h->packed3, (h->n_packed3 + 8) * sizeof(unsigned short)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(packed3)");
   if (hipMemcpyAsync(h->params, params_dev, n_floats * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
     return bail(RGFM_EHIP, "hipMemcpyAsync(params)");
-  for (const auto* v : {&h->enc, &h->mid, &h->dec})
-    for (const ResW& r : *v) {
-      pack_one(h, r.c1, s);
-      pack_one(h, r.c2, s);
-      if (r.has_skip) pack_one(h, r.sk, s);
+  std::vector<ConvW*> all;
+  for (auto* v : {&h->enc, &h->mid, &h->dec})
+    for (ResW& r : *v) {
+      all.push_back(&r.c1), all.push_back(&r.c2);
+      if (r.has_skip) all.push_back(&r.sk);
     }
-  for (const ConvW& w : h->down) {  // stride-2 convs: phase-ordered split-bf16 weights
-    pack_one(h, w, s);
-    launch_pack_conv_bx3_s2(h->params + w.w_raw, h->packed3 + w.w_bx3, w.cout, w.cin, s);
-  }
-  for (const ConvW& w : h->up) pack_one(h, w, s);
+  for (ConvW* w : all) pack_one(h, *w, CONV_S1, s);
+  for (ConvW& w : h->down) pack_one(h, w, CONV_S2, s), all.push_back(&w);  // stride-2 convs: phase-ordered weights
+  for (ConvW& w : h->up) pack_one(h, w, CONV_S1, s), all.push_back(&w);
+  if (read_hx_flags(h->hq, h->n_hq, all, s) != RGFM_OK) return bail(RGFM_EHIP, "reading the fp16 scale records failed");
   launch_pack_conv_out(h->params + h->ocw, h->packed + h->ocw_pk, desc->in_channels, h->final_ch, s);
   // frequency table exp(-ln(1e4) * i / half) in fp32, as torch evaluates it (unet_flexible.py:28-31)
   const int half = h->mc / 2;
@@ -691,7 +768,8 @@ extern "C" void rgfm_unet_destroy(rgfm_unet* h) {
   if (!h) return;
   if (h->params) (void)hipFree(h->params);
   if (h->packed) (void)hipFree(h->packed);
-  if (h->wino) (void)hipFree(h->wino);
+  if (h->packedh) (void)hipFree(h->packedh);
+  if (h->hq) (void)hipFree(h->hq);
   if (h->packed3) (void)hipFree(h->packed3);
   if (h->freqs) (void)hipFree(h->freqs);
   if (h->lin_dev) (void)hipFree(h->lin_dev);
@@ -710,6 +788,7 @@ extern "C" int rgfm_unet_workspace_bytes(const rgfm_unet* h, int batch, size_t* 
 
 extern "C" int rgfm_unet_forward(rgfm_unet* h, const float* x, const float* t_dev, int t_count, float* v_out,
                                  int batch, void* ws, size_t ws_bytes, rgfm_stream_t stream) {
+  refresh_modes();
   if (!h || !x || !t_dev || !v_out || !ws) return fail(RGFM_EINVAL, "null argument");
   if (batch < 1 || (t_count != 1 && t_count != batch)) return fail(RGFM_EINVAL, "t_count must be 1 or batch");
   hipStream_t s = (hipStream_t)stream;
@@ -811,6 +890,7 @@ extern "C" int rgfm_sample_single_workspace_bytes(const rgfm_unet* h, int batch,
 
 extern "C" int rgfm_sample_single(rgfm_unet* h, float* x_inout, int batch, int num_steps, int step_begin,
                                   int step_end, void* ws, size_t ws_bytes, rgfm_stream_t stream) {
+  refresh_modes();
   if (!h || !x_inout || !ws) return fail(RGFM_EINVAL, "null argument");
   if (batch < 1 || num_steps < 1 || step_begin < 0 || step_end > num_steps || step_begin > step_end)
     return fail(RGFM_EINVAL, "bad step range [%d,%d) of %d", step_begin, step_end, num_steps);
@@ -905,23 +985,12 @@ int pair_loop(EvalX&& eval_x, EvalY&& eval_y, float* x_inout, float* y_inout, co
   // The two velocity nets of a step are independent (reference :119-121): the second one runs on a
   // side stream forked from / joined back into the caller's stream every step, which fills the CUs
   // that one net's small-grid launches (8x8 level, kernel tails) leave idle.
-  struct Side {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-  };
-  static Side sides[16];  // one per device ordinal (one process may drive several devices)
-  const char* ov = getenv("RGFM_OVERLAP");  // RGFM_OVERLAP=0: both nets on the caller's stream
-  int dev = 0;
-  HIP_TRY(hipGetDevice(&dev));
-  const bool overlap = !(ov && ov[0] == '0') && dev >= 0 && dev < 16;
-  Side& sd = sides[overlap ? dev : 0];
-  if (overlap && !sd.stream) {
-    HIP_TRY(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming));
-  }
-  hipStream_t side = sd.stream;
-  hipEvent_t ev_fork = sd.fork, ev_join = sd.join;
+  // (the stream and its fork/join events belong to the device's DevState, created with the first handle)
+  DevState* ds = cur_dev();
+  if (!ds) return fail(RGFM_EINVAL, "no handle has been created on the current device");
+  const bool overlap = g_modes.overlap;
+  hipStream_t side = ds->side;
+  hipEvent_t ev_fork = ds->fork, ev_join = ds->join;
   for (int i = 0; i < ns; ++i) {
     const double t = (double)(step_begin + i) * dtd;
     const bool guided = n_mc > 0 && t > 1e-3;  // `t > eps` test of the reference (:124)
@@ -965,6 +1034,7 @@ extern "C" int rgfm_sample_pair(rgfm_unet* hx, rgfm_unet* hy, float* x_inout, fl
                                 const float* mc_y1, const float* mc_ratios, int n_mc, int batch, int num_steps,
                                 double gamma, int step_begin, int step_end, void* ws, size_t ws_bytes,
                                 rgfm_stream_t stream) {
+  refresh_modes();
   if (!hx || !hy || !x_inout || !y_inout || !ws) return fail(RGFM_EINVAL, "null argument");
   if (n_mc < 0 || (n_mc > 0 && (!mc_x1 || !mc_y1 || !mc_ratios))) return fail(RGFM_EINVAL, "MC set missing");
   if (batch < 1 || num_steps < 1 || step_begin < 0 || step_end > num_steps || step_begin > step_end)
@@ -1149,7 +1219,7 @@ struct RatioRun {
           c.out = o.data, c.stats_out = o.stats, c.B = n, c.Cout = o.C, c.g = g;
           c.halo_px = g.spt * (g.th + 2) * (g.W + 2);
           ProfScope p(RGFM_KCLASS_CONV_MFMA, conv_flops(n, S * S, o.C, 9 * cur.C), s);
-          launch_conv(c, CONV_S1, nullptr, s);
+          launch_conv(c, CONV_S1, s);
         }
       }
       cur = o;
@@ -1271,6 +1341,7 @@ extern "C" int rgfm_ratio_workspace_bytes(const rgfm_ratio* h, int n, size_t* by
 
 extern "C" int rgfm_ratio_eval(rgfm_ratio* h, const float* x, const float* y, float* out, int n, int what,
                                void* ws, size_t ws_bytes, rgfm_stream_t stream) {
+  refresh_modes();
   if (!h || !x || !y || !out || !ws) return fail(RGFM_EINVAL, "null argument");
   if (what < 0 || what > 2) return fail(RGFM_EINVAL, "bad output selector");
   size_t need = 0;
@@ -1292,8 +1363,12 @@ struct rgfm_fmnet {
   float* params = nullptr;
   float* packed = nullptr;  // packed conv / deconv weights + re-indexed Linear weights
   unsigned short* packed3 = nullptr;  // 3-plane bf16 conv / deconv weights (conv_mfma_bx3.hip)
+  unsigned short* packedh = nullptr;  // 2-plane scaled fp16 conv / deconv weights + scale records (conv_mfma_hx2.hip)
+  float* hq = nullptr;
+  unsigned* range_flag = nullptr;
   float* freqs = nullptr;
-  size_t n_params = 0, n_packed = 0, n_packed3 = 0;
+  size_t n_params = 0, n_packed = 0, n_packed3 = 0, n_packedh = 0;
+  int n_hq = 0;
   size_t c1w = 0, c1b = 0;           // encoder.conv1 (reference layout, conv_in kernel)
   size_t egw[4], egb[4];             // encoder.gn1..4
   ConvW ec[3];                       // encoder.conv2..4
@@ -1312,7 +1387,8 @@ constexpr int FM_FC_SPLITS = 14;                  // 12544/16 = 784 K-chunks = 1
 
 // state_dict order of FlowMatchingModel (flow_matching.py:43-54, :88-98, :147-151)
 size_t plan_fmnet(const rgfm_fmnet_desc& d, rgfm_fmnet* h) {
-  Cursor c, pk, p3;
+  Cursor c, pk, p3, ph;
+  int nhq = 0;
   rgfm_fmnet t;
   const int F = d.feature_dim, T = d.time_emb_dim;
   auto conv = [&](int cin, int cout, int taps) {
@@ -1322,6 +1398,8 @@ size_t plan_fmnet(const rgfm_fmnet_desc& d, rgfm_fmnet* h) {
     w.b = c.take(cout);
     w.w_pk = pk.take((size_t)cout * cin * taps);
     w.w_bx3 = p3.take((size_t)cout * cin * taps * 3);
+    w.w_hx2 = ph.take((size_t)cout * cin * taps * 2);
+    w.hq = nhq++;
     return w;
   };
   t.c1w = c.take((size_t)32 * d.img_channels * 9), t.c1b = c.take(32);
@@ -1344,11 +1422,12 @@ size_t plan_fmnet(const rgfm_fmnet_desc& d, rgfm_fmnet* h) {
   t.cow = c.take((size_t)d.img_channels * 32 * 9), t.cob = c.take(d.img_channels);
   t.cow_pk = pk.take((size_t)d.img_channels * 32 * 9);
   if (h) {
-    float *pa = h->params, *pp = h->packed, *fr = h->freqs;
-    unsigned short* p3p = h->packed3;
+    float *pa = h->params, *pp = h->packed, *fr = h->freqs, *hqp = h->hq;
+    unsigned short *p3p = h->packed3, *php = h->packedh;
+    unsigned* rf = h->range_flag;
     *h = t;
-    h->d = d, h->params = pa, h->packed = pp, h->freqs = fr, h->packed3 = p3p;
-    h->n_packed = pk.off, h->n_packed3 = p3.off;
+    h->d = d, h->params = pa, h->packed = pp, h->freqs = fr, h->packed3 = p3p, h->packedh = php, h->hq = hqp, h->range_flag = rf;
+    h->n_packed = pk.off, h->n_packed3 = p3.off, h->n_packedh = ph.off, h->n_hq = nhq;
   }
   return c.off;
 }
@@ -1411,6 +1490,7 @@ struct FmRun {
     ConvArgs c{};
     c.in0 = a.data, c.C0 = a.C, c.Hin = c.Win = a.S, c.ab = nullptr;
     c.wpk = h->packed + w.w_pk, c.wpk3 = h->packed3 + w.w_bx3, c.bias = h->params + w.b;
+    fill_hx2(c, h->packedh, h->hq, h->range_flag, w, nullptr);
     c.out = o.data, c.stats_out = o.stats, c.B = B, c.Cout = w.cout;
     const int sg = mode == CONV_T2 ? a.S : So;  // raster the tiles walk
     c.g = make_geom(sg, sg);
@@ -1419,12 +1499,12 @@ struct FmRun {
     if (norm) {
       const int gs = a.rep == 4 ? a.S / 2 : a.S;  // raster the statistics parts of `a` refer to
       const TileGeom gg = make_geom(gs, gs);
-      if (!try_consumer_gn(c, mode, nullptr, a.stats, nullptr, gg.nparts * a.rep, gg, h->params + norm->gamma,
+      if (!try_consumer_gn(c, mode, a.stats, nullptr, gg.nparts * a.rep, gg, h->params + norm->gamma,
                            h->params + norm->beta))
         c.ab = finalize(a, norm->gamma, norm->beta, ab_buf);
     }
     flush_conv(pend, s);
-    pend.valid = true, pend.c = c, pend.mode = mode, pend.wino = nullptr, pend.flops = fl;
+    pend.valid = true, pend.c = c, pend.mode = mode, pend.flops = fl;
     return o;
   }
 
@@ -1520,8 +1600,20 @@ extern "C" int rgfm_fmnet_create(const rgfm_fmnet_desc* desc, const float* param
   if (hipMalloc(&h->packed, (h->n_packed + 4) * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(packed)");
   if (hipMalloc(&h->freqs, half * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(freqs)");
   if (hipMalloc(&h->packed3, (h->n_packed3 + 8) * sizeof(unsigned short)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(packed3)");
+  if (hipMalloc(&h->packedh, (h->n_packedh + 8) * sizeof(unsigned short)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(packedh)");
+  if (hipMalloc(&h->hq, ((size_t)h->n_hq * 4 + 4) * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(hq)");
+  h->range_flag = cur_dev()->range_flag;
   if (hipMemcpyAsync(h->params, params_dev, n_floats * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
     return bail(RGFM_EHIP, "hipMemcpyAsync(params)");
+  {
+    auto packh = [&](const ConvW& w, int mode) {
+      launch_pack_conv_hx2(h->params + w.w_raw, h->packedh + w.w_hx2, h->hq + 4 * w.hq, w.cout, w.cin, w.taps, mode, s);
+    };
+    packh(h->ec[0], CONV_S2), packh(h->ec[1], CONV_S2), packh(h->ec[2], CONV_S1), packh(h->c3, CONV_S1);
+    packh(h->d1, CONV_T2), packh(h->d2, CONV_T2);
+    std::vector<ConvW*> all{&h->ec[0], &h->ec[1], &h->ec[2], &h->c3, &h->d1, &h->d2};
+    if (read_hx_flags(h->hq, h->n_hq, all, s) != RGFM_OK) return bail(RGFM_EHIP, "reading the fp16 scale records failed");
+  }
   for (int i = 0; i < 3; ++i) {  // encoder conv2 / conv3 are stride 2 (phase-ordered weights), conv4 stride 1
     const ConvW& w = h->ec[i];
     if (i < 2) launch_pack_conv_bx3_s2(h->params + w.w_raw, h->packed3 + w.w_bx3, w.cout, w.cin, s);
@@ -1552,6 +1644,8 @@ extern "C" void rgfm_fmnet_destroy(rgfm_fmnet* h) {
   if (h->params) (void)hipFree(h->params);
   if (h->packed) (void)hipFree(h->packed);
   if (h->packed3) (void)hipFree(h->packed3);
+  if (h->packedh) (void)hipFree(h->packedh);
+  if (h->hq) (void)hipFree(h->hq);
   if (h->freqs) (void)hipFree(h->freqs);
   delete h;
 }
@@ -1564,6 +1658,7 @@ extern "C" int rgfm_fmnet_workspace_bytes(const rgfm_fmnet* h, int batch, size_t
 
 extern "C" int rgfm_fmnet_forward(rgfm_fmnet* h, const float* x, const float* t_dev, int t_count, float* v_out,
                                   int batch, void* ws, size_t ws_bytes, rgfm_stream_t stream) {
+  refresh_modes();
   if (!h || !x || !t_dev || !v_out || !ws) return fail(RGFM_EINVAL, "null argument");
   if (batch < 1 || (t_count != 1 && t_count != batch)) return fail(RGFM_EINVAL, "t_count must be 1 or batch");
   const size_t need = fm_eval_bytes(h, batch) + counter_bytes(batch);
@@ -1582,6 +1677,7 @@ extern "C" int rgfm_fmnet_forward(rgfm_fmnet* h, const float* x, const float* t_
 
 extern "C" int rgfm_fmnet_sample_single(rgfm_fmnet* h, float* x_inout, int batch, int num_steps, int step_begin,
                                         int step_end, void* ws, size_t ws_bytes, rgfm_stream_t stream) {
+  refresh_modes();
   if (!h || !x_inout || !ws) return fail(RGFM_EINVAL, "null argument");
   if (batch < 1 || num_steps < 1 || step_begin < 0 || step_end > num_steps || step_begin > step_end)
     return fail(RGFM_EINVAL, "bad step range [%d,%d) of %d", step_begin, step_end, num_steps);
@@ -1621,6 +1717,7 @@ extern "C" int rgfm_fmnet_sample_pair(rgfm_fmnet* hx, rgfm_fmnet* hy, float* x_i
                                       const float* mc_x1, const float* mc_y1, const float* mc_ratios, int n_mc,
                                       int batch, int num_steps, double gamma, int step_begin, int step_end, void* ws,
                                       size_t ws_bytes, rgfm_stream_t stream) {
+  refresh_modes();
   if (!hx || !hy || !x_inout || !y_inout || !ws) return fail(RGFM_EINVAL, "null argument");
   if (n_mc < 0 || (n_mc > 0 && (!mc_x1 || !mc_y1 || !mc_ratios))) return fail(RGFM_EINVAL, "MC set missing");
   if (batch < 1 || num_steps < 1 || step_begin < 0 || step_end > num_steps || step_begin > step_end)

@@ -90,6 +90,14 @@ struct ConvArgs {
   const float* wpk;  // packed 3x3 weights  [Cout/(32NT)][Cin/16][9][32NT][16]
   const void* wpk3;  // the same weights as three bf16 planes [..][9][32NT][3][16] (conv_mfma_bx3.hip) or null
   const void* wskip3;
+  // conv_mfma_hx2.hip: the same weights as two scaled fp16 planes [..][9][32NT][2][16] + their scale record
+  // hq = {q = S_A s_w, 1 / q, s_w, eligible} (launch_pack_conv_hx2), and the device word the kernel ORs 1 into
+  // when a staged activation leaves the fp16 range (the host then repeats the call on the split-bf16 kernel)
+  const void* wpkh;
+  const void* wskiph;
+  const float* hq;
+  const float* hq_skip;
+  unsigned* range_flag;
   const float* bias; // [Cout]
   const float* temb; // time-embedding add: temb[(per_row ? b : 0) * temb_stride + c]; null = none
   int temb_stride;
@@ -180,11 +188,6 @@ void launch_conv_mfma(const ConvArgs& a, int mode, hipStream_t s);
 size_t conv_mfma_lds_bytes(const ConvArgs& a);
 int conv_mfma_init();  // raises the dynamic-LDS limit of every instantiation
 
-// persistent double-buffered variant (conv_mfma_v3.hip); falls back to launch_conv_mfma when unsupported
-bool conv_v3_supported(const ConvArgs& a, int mode);
-int conv_v3_init();
-void launch_conv_v3(const ConvArgs& a, int mode, int num_cus, hipStream_t s);
-
 // fp32 conv with operands split into three bf16 planes, on the bf16 matrix cores (conv_mfma_bx3.hip)
 bool conv_bx3_supported(const ConvArgs& a, int mode);
 bool conv_bx3_gn_supported(const ConvArgs& a, int mode);  // a.gn_* filled: can the kernel take the norm itself?
@@ -195,11 +198,14 @@ void launch_pack_conv_bx3(const float* w, void* out, int Cout, int Cin, int taps
 void launch_pack_deconv_bx3(const float* w, void* out, int Cin, int Cout, hipStream_t s);
 void launch_pack_conv_bx3_s2(const float* w, void* out, int Cout, int Cin, hipStream_t s);  // weights of a stride-2 3x3 conv
 
-// Winograd F(2x2,3x3) variant (conv_wino.hip) for stride-1 3x3 convs at 8/16/32 resolution, Cout % 64 == 0
-bool conv_wino_supported(const ConvArgs& a, int mode);
-int conv_wino_init();
-void launch_conv_wino(const ConvArgs& a, int mode, const float* upk, hipStream_t s);
-void launch_wino_pack(const float* w, float* out, int Cout, int Cin, hipStream_t s);
+// fp32 conv with operands split into two scaled fp16 planes, on the f16 matrix cores (conv_mfma_hx2.hip)
+bool conv_hx2_supported(const ConvArgs& a, int mode);
+bool conv_hx2_gn_supported(const ConvArgs& a, int mode);
+int conv_hx2_init();
+void launch_conv_hx2(const ConvArgs& a, int mode, hipStream_t s);
+// packs w (mode CONV_S1: [Cout][Cin][taps]; CONV_S2: the phase-major stride-2 order; CONV_T2: a ConvTranspose2d
+// weight [Cin][Cout][4][4], taps ignored) and writes the scale record hq[4] (device)
+void launch_pack_conv_hx2(const float* w, void* out, float* hq, int Cout, int Cin, int taps, int mode, hipStream_t s);
 
 void launch_conv_in(const ConvInArgs& a, int cin, hipStream_t s);
 void launch_conv_out(const ConvOutArgs& a, int cimg, hipStream_t s);

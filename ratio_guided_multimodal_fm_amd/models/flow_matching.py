@@ -9,7 +9,7 @@ linear kernels with their weights re-indexed to NHWC once at handle creation.  N
 """
 import torch.nn as nn
 
-from .._engine import FmNetEngine
+from .._engine import FmNetEngine, engine_property
 
 
 class SinusoidalPositionEmbeddings(nn.Module):
@@ -42,6 +42,8 @@ class VelocityDecoder(nn.Module):
 
 
 class FlowMatchingModel(nn.Module):
+    _engine = engine_property(lambda m: FmNetEngine(m))
+
     def __init__(self, img_channels=1, feature_dim=256, time_emb_dim=128):
         super().__init__()
         self.img_channels = img_channels
@@ -50,7 +52,6 @@ class FlowMatchingModel(nn.Module):
         self.time_embed = SinusoidalPositionEmbeddings(time_emb_dim)
         self.encoder = ImageEncoder(img_channels, feature_dim)
         self.decoder = VelocityDecoder(feature_dim, time_emb_dim, img_channels)
-        self._engine = FmNetEngine(self)
 
     def forward(self, x_t, t):
         """v_t [B,1,28,28] = model(x_t [B,1,28,28], t [B] or [1])  (reference :153-173)."""

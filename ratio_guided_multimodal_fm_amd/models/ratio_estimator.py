@@ -6,7 +6,7 @@ the HIP library.
 """
 import torch.nn as nn
 
-from .._engine import RatioEngine
+from .._engine import RatioEngine, engine_property
 
 
 class ImageEncoder(nn.Module):
@@ -23,6 +23,8 @@ class ImageEncoder(nn.Module):
 
 
 class RatioEstimator(nn.Module):
+    _engine = engine_property(lambda m: RatioEngine(m, kind="mnist28"))
+
     def __init__(self, feature_dim=256, hidden_dim=512, loss_type='disc'):
         super().__init__()
         self.feature_dim = feature_dim
@@ -35,7 +37,6 @@ class RatioEstimator(nn.Module):
             nn.Linear(feature_dim * 2, h), nn.LayerNorm(h), nn.SiLU(), nn.Dropout(0.1),
             nn.Linear(h, h // 2), nn.LayerNorm(h // 2), nn.SiLU(), nn.Dropout(0.1),
             nn.Linear(h // 2, 1))
-        self._engine = RatioEngine(self, kind="mnist28")
 
     def forward(self, x, y):
         return self._engine.eval(x, y, "score")

@@ -8,7 +8,7 @@ running statistics, Dropout is the identity).
 """
 import torch.nn as nn
 
-from .._engine import RatioEngine
+from .._engine import RatioEngine, engine_property
 
 
 class _BNEncoderParams(nn.Module):
@@ -38,6 +38,8 @@ class SVHNEncoder(_BNEncoderParams):
 
 
 class RatioEstimatorMNISTSVHN(nn.Module):
+    _engine = engine_property(lambda m: RatioEngine(m, kind="mnist_svhn"))
+
     def __init__(self, feature_dim=256, hidden_dim=512, loss_type='disc'):
         super().__init__()
         self.feature_dim = feature_dim
@@ -51,7 +53,6 @@ class RatioEstimatorMNISTSVHN(nn.Module):
             nn.Linear(h, h), nn.LayerNorm(h), nn.SiLU(), nn.Dropout(0.1),
             nn.Linear(h, h // 2), nn.LayerNorm(h // 2), nn.SiLU(),
             nn.Linear(h // 2, 1))
-        self._engine = RatioEngine(self, kind="mnist_svhn")
 
     def forward(self, x, y):
         """Scores T(x, y): x [B,1,32,32], y [B,3,32,32] -> [B]."""

@@ -13,14 +13,14 @@ import math
 import torch
 import torch.nn as nn
 
-from .._engine import UNetEngine
+from .._engine import UNetEngine, engine_property
 
 
 def timestep_embedding(timesteps, dim, max_period=10000):
     """Sinusoidal embedding, cos half first (reference unet_flexible.py:16-36).
 
     Host helper kept for API parity; the sampler computes the same table on
-    the device (csrc/time_embed.hip) from the frequency table built here.
+    the device (csrc/unet_kernels.hip (time_embed_kernel)) from the frequency table built here.
     """
     half = dim // 2
     freqs = embedding_freqs(dim, max_period).to(timesteps.device)
@@ -62,6 +62,8 @@ class _ConvHolder(nn.Module):
 
 class FlexibleUNet(nn.Module):
     """U-Net velocity field v(x_t, t) evaluated by the HIP library."""
+
+    _engine = engine_property(lambda m: UNetEngine(m))
 
     def __init__(self, in_channels=1, img_size=28, model_channels=32, channel_mult=(1, 2),
                  num_res_blocks=2, dropout=0.1):
@@ -109,7 +111,6 @@ class FlexibleUNet(nn.Module):
         nn.init.zeros_(self.out_conv.weight)
         nn.init.zeros_(self.out_conv.bias)
 
-        self._engine = UNetEngine(self)
 
     def forward(self, x, t):
         """x: [B,C,H,W] fp32 on a HIP device, t: [B] (or [1]) -> velocity [B,C,H,W]."""

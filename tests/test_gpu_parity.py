@@ -74,7 +74,7 @@ def test_unet_ragged_batches(dev, tag, B):
 
 
 @pytest.mark.parametrize("tag", ["g24", "g16", "g40"])
-@pytest.mark.parametrize("env", [{}, {"RGFM_CONV": "f32"}, {"RGFM_GN": "table"}])
+@pytest.mark.parametrize("env", [{}, {"RGFM_CONV": "bx3"}, {"RGFM_CONV": "f32"}, {"RGFM_GN": "table"}])
 def test_generic_flexible_unets(dev, tag, env, monkeypatch):
     """FlexibleUNet shapes outside the presets -- 24x24 (three tiles per sample: tile pairs straddle samples, 12
     statistics parts), 16x16 with four levels down to 2x2 maps and three blocks per level, 40x40 (tiles of 6 rows,
@@ -409,14 +409,14 @@ def test_full_size_arithmetic_modes_agree(dev, monkeypatch):
     assert maxdiff(res["default"][1], res["fp32"][1]) < TOL_SAMPLER
 
 
-@pytest.mark.parametrize("env", [{"RGFM_CONV": "f32"}, {"RGFM_CONV": "f32", "RGFM_WINO": "1"}, {"RGFM_CONV": "v3"},
+@pytest.mark.parametrize("env", [{"RGFM_CONV": "f32"}, {"RGFM_CONV": "bx3"}, {"RGFM_CONV": "bx3", "RGFM_GN": "table"},
                                  {"RGFM_GN": "table"}, {"RGFM_GN": "table", "RGFM_FUSE_FIN": "0"},
                                  {"RGFM_CONV": "f32", "RGFM_FUSE_FIN": "0"}])
 @pytest.mark.parametrize("tag,B", [("svhn", 5), ("mnist32", 3)])
-def test_experimental_conv_variants_keep_parity(dev, env, tag, B, monkeypatch):
-    """The alternative conv paths (exact-fp32 MFMA: RGFM_CONV=f32; with Winograd F(2x2,3x3): + RGFM_WINO=1;
-    persistent one-block-per-CU fp32 kernel: RGFM_CONV=v3; all read per launch) and the alternative GroupNorm
-    plumbing (RGFM_GN=table: scale/shift arrays written by the producing conv's last wave, or -- with
+def test_conv_variants_keep_parity(dev, env, tag, B, monkeypatch):
+    """The alternative conv arithmetic (RGFM_CONV=bx3: three exact bf16 planes, the fp32-range fallback of the
+    default two-plane fp16 path; RGFM_CONV=f32: exact-fp32 MFMA; read once per API call) and the alternative
+    GroupNorm plumbing (RGFM_GN=table: scale/shift arrays written by the producing conv's last wave, or -- with
     RGFM_FUSE_FIN=0 -- by gn_finalize launches, instead of the consumer conv's prologue) must stay inside the
     same tolerance as the default path."""
     m = make_module(tag, dev)
@@ -432,10 +432,11 @@ def test_experimental_conv_variants_keep_parity(dev, env, tag, B, monkeypatch):
 
 @pytest.mark.parametrize("tag", ["unet28", "mnist32", "svhn", "fm_original"])
 def test_arithmetic_error_against_float64(dev, tag, monkeypatch):
-    """Error budget of the two conv arithmetic modes against the reference evaluated in float64
-    (tests/golden/fp64_eval.npz): RGFM_CONV=f32 (v_mfma_f32_32x32x2_f32, exact fp32 products) and
-    RGFM_CONV=bx3 (operands as three exact bf16 planes, six bf16-MFMA products, fp32 accumulate).
-    Both must sit in the reference's own fp32-vs-fp64 error class (its own error is ~1.4e-6..2e-6)."""
+    """Error budget of the three conv arithmetic modes against the reference evaluated in float64
+    (tests/golden/fp64_eval.npz): RGFM_CONV=f32 (v_mfma_f32_32x32x2_f32, exact fp32 products), RGFM_CONV=bx3
+    (operands as three exact bf16 planes, six bf16-MFMA products) and the default hx2 (operands as two scaled fp16
+    planes, three f16-MFMA products), all with fp32 accumulation.  All must sit in the reference's own
+    fp32-vs-fp64 error class (its own error is ~1.4e-6..2e-6)."""
     g = golden("fp64_eval")
     shape = (1, 28, 28) if tag in ("unet28", "fm_original") else SHAPES[tag]
     x = torch.randn(4, *shape, generator=torch.Generator().manual_seed(91))
@@ -444,13 +445,97 @@ def test_arithmetic_error_against_float64(dev, tag, monkeypatch):
     m = make_module(tag, dev)
     ref_err = float(g[f"{tag}_ref32_err"])
     errs = {}
-    for mode in ("f32", "bx3"):
+    before = _engine.range_fallbacks
+    for mode in ("f32", "bx3", "hx2"):
         monkeypatch.setenv("RGFM_CONV", mode)
         out = m(x.to(dev), t.to(dev)).cpu().numpy().astype(np.float64)
         errs[mode] = float(np.abs(out - g[f"{tag}_f64"]).max())
-    print(f"{tag}: max|err| vs float64  reference-fp32 {ref_err:.2e}  f32-MFMA {errs['f32']:.2e}  bx3 {errs['bx3']:.2e}")
-    assert errs["f32"] < 5e-6 and errs["bx3"] < 5e-6
-    assert errs["bx3"] < 2.0 * max(errs["f32"], ref_err)
+    assert _engine.range_fallbacks == before  # the fp16 path really ran (no silent fallback to bx3)
+    print(f"{tag}: max|err| vs float64  reference-fp32 {ref_err:.2e}  f32-MFMA {errs['f32']:.2e}  bx3 {errs['bx3']:.2e}"
+          f"  hx2 {errs['hx2']:.2e}")
+    assert errs["f32"] < 5e-6 and errs["bx3"] < 5e-6 and errs["hx2"] < 5e-6
+    assert errs["bx3"] < 2.0 * max(errs["f32"], ref_err) and errs["hx2"] < 2.0 * max(errs["f32"], ref_err)
+
+
+def _scaled_unet(tag, dev, wscale, seed=31):
+    """Preset U-Net with the 3x3 conv weights and biases of every ResBlock multiplied by `wscale`.  The next
+    GroupNorm renormalises, so the network output stays O(1), but the residual stream -- which the 1x1 skip convs
+    and the down/up-sampling convs consume un-normalised -- scales with it.  (Scaling EVERY layer would overflow
+    fp32 itself: each skip conv multiplies the stream by the scale once more.)"""
+    from ratio_guided_multimodal_fm_amd import models as M
+    from ratio_guided_multimodal_fm_amd.synth import load_synth
+    m = load_synth(M.FlowMatchingUNetMNIST(32) if tag == "mnist32" else M.FlowMatchingUNetSVHN(), seed)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if ".conv1." in name or ".conv2." in name:
+                p.mul_(wscale)
+    return m.to(dev).eval()
+
+
+@pytest.mark.parametrize("tag", ["mnist32", "svhn"])
+@pytest.mark.parametrize("lg", [-100, -30, 30, 50])
+def test_conv_range_of_the_split_paths(dev, tag, lg, monkeypatch):
+    """Range statement of the split-operand conv paths: with the ResBlock conv weights
+    scaled by 2^lg the bf16 path and the default fp16 path must agree with the exact-fp32 MFMA path to relative
+    1e-5.  lg = -30: still the fp16 kernel (per-conv power-of-two weight scales).  lg = -100 / 50: those convs
+    are outside the fp16 path's weight range [2^-40, 2^40] and are routed to the bf16 kernel at create time.
+    lg = 30 / 50: the residual stream (~2^lg) leaves the fp16 activation range, the range flag goes up and the
+    call is repeated on the bf16 kernel -- automatically, never a silently wrong number.  (Beyond 2^60 the fp32
+    GroupNorm statistics themselves overflow, in every mode and in the reference.)"""
+    m = _scaled_unet(tag, dev, 2.0 ** lg)
+    x = torch.randn(3, *SHAPES[tag], generator=torch.Generator().manual_seed(3)).to(dev)
+    t = torch.tensor([0.1, 0.5, 0.9], device=dev)
+    monkeypatch.setenv("RGFM_CONV", "f32")
+    ref = m(x, t).cpu().numpy().astype(np.float64)
+    assert np.isfinite(ref).all() and np.abs(ref).max() > 0
+    for mode in ("bx3", "hx2"):
+        monkeypatch.setenv("RGFM_CONV", mode)
+        out = m(x, t).cpu().numpy().astype(np.float64)
+        rel = float(np.abs(out - ref).max() / np.abs(ref).max())
+        assert rel < 1e-5, (tag, lg, mode, rel)
+
+
+def test_fp16_range_flag_falls_back_to_bf16(dev, monkeypatch):
+    """Activations beyond the fp16 path's range (|a| >= 2048): input_conv weights x 2^14 make the un-normalised
+    residual stream ~1e4-1e5, which the 1x1 skip convs and down/up-samplers consume raw.  The default path must
+    notice (range flag), repeat the call on the bf16 kernel and still agree with the exact-fp32 path."""
+    from ratio_guided_multimodal_fm_amd import models as M
+    from ratio_guided_multimodal_fm_amd.synth import load_synth
+    m = load_synth(M.FlowMatchingUNetSVHN(), 31)
+    with torch.no_grad():
+        m.input_conv.weight.mul_(2.0 ** 14)
+        m.input_conv.bias.mul_(2.0 ** 14)
+    m = m.to(dev).eval()
+    x = torch.randn(2, 3, 32, 32, generator=torch.Generator().manual_seed(4)).to(dev)
+    t = torch.tensor([0.2, 0.8], device=dev)
+    monkeypatch.setenv("RGFM_CONV", "f32")
+    ref = m(x, t).cpu().numpy().astype(np.float64)
+    monkeypatch.delenv("RGFM_CONV")
+    before = _engine.range_fallbacks
+    out = m(x, t).cpu().numpy().astype(np.float64)
+    assert _engine.range_fallbacks == before + 1
+    assert float(np.abs(out - ref).max() / np.abs(ref).max()) < 1e-5
+    # in-place samplers restore their state before the repeat
+    xs = x.clone()
+    monkeypatch.setenv("RGFM_CONV", "f32")
+    r2 = _engine.sample_single(m, x.clone(), 8, 0, 2).cpu().numpy().astype(np.float64)
+    monkeypatch.delenv("RGFM_CONV")
+    o2 = _engine.sample_single(m, xs, 8, 0, 2).cpu().numpy().astype(np.float64)
+    assert _engine.range_fallbacks == before + 2
+    assert float(np.abs(o2 - r2).max() / np.abs(r2).max()) < 1e-5
+
+
+def test_same_module_for_both_modalities(dev):
+    """sample_bimodal_guided(fm, fm, ...) is legal in the reference: one module (one engine workspace) for both
+    modalities must not race in the two-stream pre-phase."""
+    from ratio_guided_multimodal_fm_amd.utils.flow_utils import paired_sampler
+    fm, rr = make_module("unet28", dev), make_module("ratio28", dev)
+    noise = paired_noise(21, 6, 7, (1, 28, 28), (1, 28, 28))
+    xs, ys = paired_sampler(fm, fm, rr, "mc_feng", 0.5, 6, 5, dev, 7, (1, 28, 28), (1, 28, 28), noise=noise, verbose=False)
+    d, b = oracle_net("unet28")
+    _, rb = oracle_net("ratio28")
+    ox, oy, _ = O.paired_sampler(d, b, d, b, "mnist28", rb, "disc", tuple(v.numpy() for v in noise), True, 0.5, 5)
+    assert maxdiff(xs.cpu().numpy(), ox) < TOL_SAMPLER and maxdiff(ys.cpu().numpy(), oy) < TOL_SAMPLER
 
 
 def test_rccl_collectives_single_rank(dev):

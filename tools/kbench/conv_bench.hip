@@ -1,15 +1,18 @@
 // Single-layer benchmark of the conv kernels (development tool; not part of the library).
-//   conv_bench <S> <Cin> <Cout> [mode 0|2] [res 0|1|2] [B] [which: bx3|f32]
+//   conv_bench <S> <Cin> <Cout> [mode 0|2] [res 0|1|2] [B] [which: bx3|f32|hx2]
+// Every run also checks the selected kernel against the exact-fp32 MFMA kernel on the same data.
 // Builds one ConvArgs with random NHWC input / packed weights, launches it 20x, prints us and
 // fp32-equivalent TFLOP/s; with -DRGFM_BX3_PROF also the per-phase cycle counts of the bx3w kernel.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <vector>
 
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_bx3.hip"
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma.hip"
+#include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2.hip"
 
 using namespace rgfm;
 
@@ -48,11 +51,13 @@ int main(int argc, char** argv) {
   const int S = argc > 1 ? atoi(argv[1]) : 32, Cin = argc > 2 ? atoi(argv[2]) : 64, Cout = argc > 3 ? atoi(argv[3]) : 64;
   const int mode = argc > 4 ? atoi(argv[4]) : 0, res = argc > 5 ? atoi(argv[5]) : 0, B = argc > 6 ? atoi(argv[6]) : 512;
   const bool f32 = argc > 7 && strcmp(argv[7], "f32") == 0;
+  const bool hx2 = argc > 7 && strcmp(argv[7], "hx2") == 0;
   const int Sin = mode == CONV_UP2 ? S / 2 : S;
   const int nt = Cout % 64 == 0 ? 2 : 1;
   CK(hipSetDevice(0));
   conv_mfma_init();
   conv_bx3_init();
+  conv_hx2_init();
   ConvArgs a{};
   a.in0 = dev_rand((size_t)B * Sin * Sin * Cin, 1.f, 1);
   a.C0 = Cin, a.Hin = a.Win = Sin;
@@ -65,6 +70,16 @@ int main(int argc, char** argv) {
   hipMalloc(&w3, (size_t)Cout * Cin * 9 * 6);
   launch_pack_conv_bx3(w, w3, Cout, Cin, 9, 0);
   a.wpk = wp, a.wpk3 = w3;
+  void* wh;
+  hipMalloc(&wh, (size_t)Cout * Cin * 9 * 4);
+  float* hq;
+  hipMalloc(&hq, 8 * sizeof(float));
+  launch_pack_conv_hx2(w, wh, hq, Cout, Cin, 9, CONV_S1, 0);
+  a.wpkh = wh, a.hq = hq;
+  unsigned* flag;
+  hipMalloc(&flag, 4);
+  hipMemset(flag, 0, 4);
+  a.range_flag = flag;
   a.bias = dev_rand(Cout, 0.1f, 4);
   a.temb = dev_rand(Cout, 0.1f, 5), a.temb_stride = Cout;
   a.res_mode = res;
@@ -81,6 +96,10 @@ int main(int argc, char** argv) {
     hipMalloc(&ws3, (size_t)Cout * R * 6);
     launch_pack_conv_bx3(ws, ws3, Cout, R, 1, 0);
     a.wskip = wsp, a.wskip3 = ws3, a.skip_bias = dev_rand(Cout, 0.1f, 8);
+    void* wsh;
+    hipMalloc(&wsh, (size_t)Cout * R * 4);
+    launch_pack_conv_hx2(ws, wsh, hq + 4, Cout, R, 1, CONV_S1, 0);
+    a.wskiph = wsh, a.hq_skip = hq + 4;
     skipk = R;
   }
   float* out;
@@ -93,10 +112,35 @@ int main(int argc, char** argv) {
   a.B = B, a.Cout = Cout;
   a.halo_px = a.g.spt * (a.g.th + 2) * (a.g.W + 2);
   const double flops = 2.0 * B * S * S * (double)Cout * (9 * Cin + skipk);
-  auto launch = [&]() { if (f32) launch_conv_mfma(a, mode, 0); else launch_conv_bx3(a, mode, 0); };
-  launch();
-  CK(hipDeviceSynchronize());
-  CK(hipGetLastError());
+  auto launch = [&]() { if (f32) launch_conv_mfma(a, mode, 0); else if (hx2) launch_conv_hx2(a, mode, 0); else launch_conv_bx3(a, mode, 0); };
+  {  // reference: the exact-fp32 MFMA kernel on the same data
+    const size_t no = (size_t)B * S * S * Cout, ns = (size_t)B * a.g.nparts * Cout * 2;
+    std::vector<float> ref(no), got(no), sref(ns), sgot(ns);
+    launch_conv_mfma(a, mode, 0);
+    CK(hipDeviceSynchronize());
+    CK(hipGetLastError());
+    hipMemcpy(ref.data(), out, no * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(sref.data(), st, ns * 4, hipMemcpyDeviceToHost);
+    hipMemset(out, 0, no * 4);
+    launch();
+    CK(hipDeviceSynchronize());
+    CK(hipGetLastError());
+    hipMemcpy(got.data(), out, no * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(sgot.data(), st, ns * 4, hipMemcpyDeviceToHost);
+    double emax = 0, vmax = 0, smax = 0;
+    for (size_t i = 0; i < no; ++i) {
+      const double d = fabs((double)got[i] - ref[i]);
+      if (!(d <= emax)) emax = d;
+      if (fabs(ref[i]) > vmax) vmax = fabs(ref[i]);
+    }
+    for (size_t i = 0; i < ns; ++i) {
+      const double d = fabs((double)sgot[i] - sref[i]) / (1.0 + fabs(sref[i]));
+      if (!(d <= smax)) smax = d;
+    }
+    unsigned fl = 0;
+    hipMemcpy(&fl, flag, 4, hipMemcpyDeviceToHost);
+    printf("check vs f32 kernel: max|diff| %.3e (max|ref| %.3f), stats rel diff %.3e, range flag %u\n", emax, vmax, smax, fl);
+  }
 #ifdef RGFM_BX3_PROF
   unsigned long long zero[10] = {0};
   hipMemcpyToSymbol(HIP_SYMBOL(g_bx3_prof), zero, sizeof(zero));
@@ -111,7 +155,7 @@ int main(int argc, char** argv) {
   float ms;
   hipEventElapsedTime(&ms, e0, e1);
   const double us = ms * 1e3 / reps;
-  printf("%s S=%d Cin=%d Cout=%d mode=%d res=%d B=%d: %8.1f us  %6.1f TFLOP/s (fp32-equivalent)\n", f32 ? "f32" : "bx3", S, Cin,
+  printf("%s S=%d Cin=%d Cout=%d mode=%d res=%d B=%d: %8.1f us  %6.1f TFLOP/s (fp32-equivalent)\n", f32 ? "f32" : (hx2 ? "hx2" : "bx3"), S, Cin,
          Cout, mode, res, B, us, flops / us / 1e6);
 #ifdef RGFM_BX3_PROF
   unsigned long long p[10];
