@@ -1,0 +1,36 @@
+// conv_hx2_common.h -- device helpers shared by conv_mfma_hx2.hip and conv_mfma_hx2p.hip (two-plane fp16 split,
+// LDS record layout).  See the header comment of conv_mfma_hx2.hip for the arithmetic.
+#pragma once
+#include "rgfm_device.h"
+
+namespace rgfm {
+
+typedef __attribute__((address_space(1))) f32x4 hx_gf32x4;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float hx_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned hx_u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr float HX_SA = 16.f;         // activation scale S_A
+constexpr float HX_LIMIT = 32768.f;   // |a'| at or above this raises the range flag
+
+// 2-way fp16 split of two (already scaled) floats: planes h, l as packed fp16 pairs (v_cvt_pk_f16_f32, RNE)
+__device__ __forceinline__ void hsplit2(float a, float b, unsigned& ph, unsigned& pl) {
+  hx_f32x2 v = {a, b};
+  const f16x2 h = __builtin_convertvector(v, f16x2);
+  ph = __builtin_bit_cast(unsigned, h);
+  v = v - __builtin_convertvector(h, hx_f32x2);
+  pl = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+
+// S_A silu(z) from z' = S_A z (v_exp_f32 + v_rcp_f32 as silu_fast)
+__device__ __forceinline__ float silu_scaled(float zs) {
+  const float e = __builtin_amdgcn_exp2f(zs * (-1.44269504088896341f / HX_SA));
+  return zs * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+constexpr int HRW = 64;  // bytes per LDS record: [plane h | plane l] x 16 fp16
+// byte offset of 16-byte slot (plane, half) inside record `rec`
+__device__ __forceinline__ int hswz(int rec, int plane, int half) { return (((2 * plane + half) ^ (rec >> 2)) & 3) * 16; }
+
+}  // namespace rgfm

@@ -233,6 +233,7 @@ enum { CONV_ARITH_HX2 = 0, CONV_ARITH_BX3 = 1, CONV_ARITH_F32 = 2 };
 struct Modes {
   int conv = CONV_ARITH_HX2;
   bool overlap = true, fuse_fin = true, gn_consumer = true;
+  bool pipelined = true;  // RGFM_HX2P=0: the fp16 convs on conv_mfma_hx2_kernel only (A/B switch)
 };
 Modes g_modes;
 void refresh_modes() {
@@ -246,6 +247,8 @@ void refresh_modes() {
   m.fuse_fin = !(e && e[0] == '0');
   e = getenv("RGFM_GN");
   m.gn_consumer = !(e && strcmp(e, "table") == 0);
+  e = getenv("RGFM_HX2P");
+  m.pipelined = !(e && e[0] == '0');
   g_modes = m;
 }
 
@@ -275,7 +278,7 @@ int ensure_init() {
   if (dev < 0 || dev >= MAX_DEVICES) return fail(RGFM_EINVAL, "device ordinal %d out of range (max %d)", dev, MAX_DEVICES - 1);
   DevState& d = g_dev[dev];
   if (!d.init) {
-    if (conv_mfma_init() != 0 || conv_bx3_init() != 0 || conv_hx2_init() != 0)
+    if (conv_mfma_init() != 0 || conv_bx3_init() != 0 || conv_hx2_init() != 0 || conv_hx2p_init() != 0)
       return fail(RGFM_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, dev) == hipSuccess) d.num_cus = p.multiProcessorCount;
@@ -290,7 +293,8 @@ int ensure_init() {
 }
 
 void launch_conv(const ConvArgs& c, int mode, hipStream_t s) {
-  if (g_modes.conv == CONV_ARITH_HX2 && conv_hx2_supported(c, mode)) launch_conv_hx2(c, mode, s);
+  if (g_modes.conv == CONV_ARITH_HX2 && g_modes.pipelined && conv_hx2p_supported(c, mode)) launch_conv_hx2p(c, mode, s);
+  else if (g_modes.conv == CONV_ARITH_HX2 && conv_hx2_supported(c, mode)) launch_conv_hx2(c, mode, s);
   else if (g_modes.conv != CONV_ARITH_F32 && conv_bx3_supported(c, mode)) launch_conv_bx3(c, mode, s);
   else launch_conv_mfma(c, mode, s);
 }

@@ -203,6 +203,10 @@ bool conv_hx2_supported(const ConvArgs& a, int mode);
 bool conv_hx2_gn_supported(const ConvArgs& a, int mode);
 int conv_hx2_init();
 void launch_conv_hx2(const ConvArgs& a, int mode, hipStream_t s);
+// producer / consumer pipelined version for CONV_S1 / CONV_UP2 (conv_mfma_hx2p.hip); same arguments
+bool conv_hx2p_supported(const ConvArgs& a, int mode);
+int conv_hx2p_init();
+void launch_conv_hx2p(const ConvArgs& a, int mode, hipStream_t s);
 // packs w (mode CONV_S1: [Cout][Cin][taps]; CONV_S2: the phase-major stride-2 order; CONV_T2: a ConvTranspose2d
 // weight [Cin][Cout][4][4], taps ignored) and writes the scale record hq[4] (device)
 void launch_pack_conv_hx2(const float* w, void* out, float* hq, int Cout, int Cin, int taps, int mode, hipStream_t s);

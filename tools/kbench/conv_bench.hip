@@ -1,5 +1,5 @@
 // Single-layer benchmark of the conv kernels (development tool; not part of the library).
-//   conv_bench <S> <Cin> <Cout> [mode 0|2] [res 0|1|2] [B] [which: bx3|f32|hx2]
+//   conv_bench <S> <Cin> <Cout> [mode 0|2] [res 0|1|2] [B] [which: bx3|f32|hx2|hx2p]
 // Every run also checks the selected kernel against the exact-fp32 MFMA kernel on the same data.
 // Builds one ConvArgs with random NHWC input / packed weights, launches it 20x, prints us and
 // fp32-equivalent TFLOP/s; with -DRGFM_BX3_PROF also the per-phase cycle counts of the bx3w kernel.
@@ -13,6 +13,8 @@
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_bx3.hip"
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma.hip"
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2.hip"
+#include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2p.hip"
+#include "../../ratio_guided_multimodal_fm_amd/csrc/unet_kernels.hip"
 
 using namespace rgfm;
 
@@ -52,16 +54,44 @@ int main(int argc, char** argv) {
   const int mode = argc > 4 ? atoi(argv[4]) : 0, res = argc > 5 ? atoi(argv[5]) : 0, B = argc > 6 ? atoi(argv[6]) : 512;
   const bool f32 = argc > 7 && strcmp(argv[7], "f32") == 0;
   const bool hx2 = argc > 7 && strcmp(argv[7], "hx2") == 0;
+  const bool hx2p = argc > 7 && strcmp(argv[7], "hx2p") == 0;
   const int Sin = mode == CONV_UP2 ? S / 2 : S;
   const int nt = Cout % 64 == 0 ? 2 : 1;
   CK(hipSetDevice(0));
   conv_mfma_init();
   conv_bx3_init();
   conv_hx2_init();
+  conv_hx2p_init();
   ConvArgs a{};
   a.in0 = dev_rand((size_t)B * Sin * Sin * Cin, 1.f, 1);
   a.C0 = Cin, a.Hin = a.Win = Sin;
-  a.ab = dev_rand((size_t)B * Cin * 2, 1.f, 2);
+  // input GroupNorm: random partial statistics (mean, M2) of the input map, finalized into the scale/shift array
+  // the table-path kernels read; the pipelined kernel derives the same numbers from the statistics itself
+  const TileGeom gin = make_geom(Sin, Sin);
+  float* gstats;
+  {
+    const size_t ns = (size_t)B * gin.nparts * Cin * 2;
+    std::vector<float> hs(ns);
+    unsigned sd = 777u;
+    for (size_t i = 0; i < ns; i += 2) {
+      sd = sd * 1664525u + 1013904223u;
+      hs[i] = 0.3f * ((float)(sd >> 8) / 8388608.0f - 1.0f);
+      sd = sd * 1664525u + 1013904223u;
+      hs[i + 1] = 64.f * (0.2f + 0.2f * (float)(sd >> 8) / 16777216.0f);
+    }
+    hipMalloc(&gstats, ns * 4);
+    hipMemcpy(gstats, hs.data(), ns * 4, hipMemcpyHostToDevice);
+  }
+  float* ggamma = dev_rand(Cin, 1.f, 21);
+  float* gbeta = dev_rand(Cin, 0.3f, 22);
+  float* abbuf;
+  hipMalloc(&abbuf, (size_t)B * Cin * 2 * 4);
+  {
+    GnFinalizeArgs f{};
+    f.stats0 = gstats, f.C0 = Cin, f.groups = 8, f.gamma = ggamma, f.beta = gbeta, f.ab = abbuf, f.B = B, f.g = gin;
+    launch_gn_finalize(f, 0);
+  }
+  a.ab = abbuf;
   float* w = dev_rand((size_t)Cout * Cin * 9, 0.05f, 3);
   float* wp;
   hipMalloc(&wp, (size_t)Cout * Cin * 9 * 4);
@@ -112,7 +142,15 @@ int main(int argc, char** argv) {
   a.B = B, a.Cout = Cout;
   a.halo_px = a.g.spt * (a.g.th + 2) * (a.g.W + 2);
   const double flops = 2.0 * B * S * S * (double)Cout * (9 * Cin + skipk);
-  auto launch = [&]() { if (f32) launch_conv_mfma(a, mode, 0); else if (hx2) launch_conv_hx2(a, mode, 0); else launch_conv_bx3(a, mode, 0); };
+  ConvArgs ap = a;  // the pipelined kernel takes the norm itself
+  ap.ab = nullptr, ap.gn_stats0 = gstats, ap.gn_gamma = ggamma, ap.gn_beta = gbeta, ap.gn_nparts0 = gin.nparts, ap.gn_g = gin;
+  if (hx2p && !conv_hx2p_supported(ap, mode)) { printf("hx2p: unsupported shape\n"); return 1; }
+  auto launch = [&]() {
+    if (f32) launch_conv_mfma(a, mode, 0);
+    else if (hx2) launch_conv_hx2(a, mode, 0);
+    else if (hx2p) launch_conv_hx2p(ap, mode, 0);
+    else launch_conv_bx3(a, mode, 0);
+  };
   {  // reference: the exact-fp32 MFMA kernel on the same data
     const size_t no = (size_t)B * S * S * Cout, ns = (size_t)B * a.g.nparts * Cout * 2;
     std::vector<float> ref(no), got(no), sref(ns), sgot(ns);
@@ -141,9 +179,17 @@ int main(int argc, char** argv) {
     hipMemcpy(&fl, flag, 4, hipMemcpyDeviceToHost);
     printf("check vs f32 kernel: max|diff| %.3e (max|ref| %.3f), stats rel diff %.3e, range flag %u\n", emax, vmax, smax, fl);
   }
-#ifdef RGFM_BX3_PROF
+#ifdef RGFM_HX2P_PROF
+  unsigned long long zerop[10] = {0};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_hx2p_prof), zerop, sizeof(zerop));
+#endif
+#if defined(RGFM_BX3_PROF) || defined(RGFM_HX2_PROF)
   unsigned long long zero[10] = {0};
+#ifdef RGFM_HX2_PROF
+  hipMemcpyToSymbol(HIP_SYMBOL(g_hx2_prof), zero, sizeof(zero));
+#else
   hipMemcpyToSymbol(HIP_SYMBOL(g_bx3_prof), zero, sizeof(zero));
+#endif
 #endif
   hipEvent_t e0, e1;
   hipEventCreate(&e0), hipEventCreate(&e1);
@@ -155,11 +201,24 @@ int main(int argc, char** argv) {
   float ms;
   hipEventElapsedTime(&ms, e0, e1);
   const double us = ms * 1e3 / reps;
-  printf("%s S=%d Cin=%d Cout=%d mode=%d res=%d B=%d: %8.1f us  %6.1f TFLOP/s (fp32-equivalent)\n", f32 ? "f32" : (hx2 ? "hx2" : "bx3"), S, Cin,
+  printf("%s S=%d Cin=%d Cout=%d mode=%d res=%d B=%d: %8.1f us  %6.1f TFLOP/s (fp32-equivalent)\n", f32 ? "f32" : (hx2 ? "hx2" : (hx2p ? "hx2p" : "bx3")), S, Cin,
          Cout, mode, res, B, us, flops / us / 1e6);
-#ifdef RGFM_BX3_PROF
+#ifdef RGFM_HX2P_PROF
+  {
+    unsigned long long pp[10];
+    hipMemcpyFromSymbol(pp, HIP_SYMBOL(g_hx2p_prof), sizeof(pp));
+    const double nbk = (double)pp[9];
+    const char* nm[9] = {"w0:pro+fill", "w0:stage", "w0:mfma", "w0:barrier", "w4:pro+fill", "w4:stage", "w4:mfma", "w4:barrier", "w0:epilogue"};
+    for (int i = 0; i < 9; ++i) printf("  %-12s %10.0f clk/block\n", nm[i], pp[i] / nbk);
+  }
+#endif
+#if defined(RGFM_BX3_PROF) || defined(RGFM_HX2_PROF)
   unsigned long long p[10];
+#ifdef RGFM_HX2_PROF
+  hipMemcpyFromSymbol(p, HIP_SYMBOL(g_hx2_prof), sizeof(p));
+#else
   hipMemcpyFromSymbol(p, HIP_SYMBOL(g_bx3_prof), sizeof(p));
+#endif
   const double nb = (double)p[7];
   const char* names[7] = {"prologue", "issue", "mfma", "commit-wait", "commit-A", "commit-B", "epilogue"};
   double tot = 0;
