@@ -97,6 +97,11 @@ int rgfm_unet_forward(rgfm_unet* h, const float* x, const float* t_dev, int t_co
  * out_dev.  Only valid when the handle was put in trace mode, which keeps every
  * activation in its own buffer. */
 int rgfm_unet_set_trace(rgfm_unet* h, int enable);
+/* Parity hook: emb_out[t_count][model_channels] = timestep_embedding(t, model_channels) exactly as the
+ * device evaluates it in front of the time MLPs (unet_flexible.py:16-36: cos half first, t unscaled).
+ * ws: at least rgfm_unet_workspace_bytes(h, t_count) bytes. */
+int rgfm_unet_time_embedding(rgfm_unet* h, const float* t_dev, int t_count, float* emb_out, void* ws,
+                             size_t ws_bytes, rgfm_stream_t stream);
 int rgfm_unet_num_activations(const rgfm_unet* h, int* n);
 int rgfm_unet_activation_shape(const rgfm_unet* h, int index, int* channels, int* height, int* width);
 int rgfm_unet_read_activation(rgfm_unet* h, int index, int batch, const void* ws, float* out_dev,

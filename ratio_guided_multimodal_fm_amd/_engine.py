@@ -263,6 +263,18 @@ class UNetEngine(_VelocityEngine):
         return d
 
     # ---- parity hooks -------------------------------------------------
+    def time_embedding(self, t):
+        """timestep_embedding(t, model_channels) as the device evaluates it (rgfm_unet_time_embedding)."""
+        _require_hip(t)
+        t = t.reshape(-1).contiguous()
+        dev = t.device
+        out = torch.empty(t.numel(), self._module().model_channels, device=dev)
+        with torch.cuda.device(dev):
+            h = self.handle(dev)
+            ws, nb = self.workspace("rgfm_unet_workspace_bytes", t.numel(), dev)
+            _lib.check(_lib.lib().rgfm_unet_time_embedding(h, _ptr(t), t.numel(), _ptr(out), _ptr(ws), nb, _stream(dev)))
+        return out
+
     def forward_trace(self, x, t):
         """Forward in trace mode; returns (out, [activation tensors, NCHW])."""
         dev = x.device

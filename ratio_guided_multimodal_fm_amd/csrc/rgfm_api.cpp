@@ -813,6 +813,20 @@ extern "C" int rgfm_unet_forward(rgfm_unet* h, const float* x, const float* t_de
   return RGFM_OK;
 }
 
+extern "C" int rgfm_unet_time_embedding(rgfm_unet* h, const float* t_dev, int t_count, float* emb_out, void* ws,
+                                        size_t ws_bytes, rgfm_stream_t stream) {
+  if (!h || !t_dev || !emb_out || !ws || t_count < 1) return fail(RGFM_EINVAL, "bad argument");
+  if (table_bytes(h, t_count) > ws_bytes) return fail(RGFM_ENOMEM, "workspace too small");
+  TimeEmbedArgs a{};
+  a.params = h->params, a.freqs = h->freqs, a.mc = h->mc, a.temb = h->temb;
+  a.te0w = (int)h->te0w, a.te0b = (int)h->te0b, a.te2w = (int)h->te2w, a.te2b = (int)h->te2b;
+  a.lin = h->lin_dev, a.nlin = h->nlin, a.total = h->temb_total;
+  a.t_dev = t_dev, a.num_steps = 1, a.step_begin = 0, a.table = reinterpret_cast<float*>(ws), a.emb_out = emb_out;
+  launch_time_embed(a, t_count, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return RGFM_OK;
+}
+
 extern "C" int rgfm_unet_set_trace(rgfm_unet* h, int enable) {
   if (!h) return fail(RGFM_EINVAL, "null handle");
   h->trace = enable != 0;

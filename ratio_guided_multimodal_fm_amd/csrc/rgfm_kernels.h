@@ -182,6 +182,7 @@ struct TimeEmbedArgs {
   const float* t_dev;
   int num_steps, step_begin;
   float* table;            // [nt][total]
+  float* emb_out;          // optional [nt][mc]: the sinusoidal embedding itself (parity hook)
 };
 
 void launch_conv_mfma(const ConvArgs& a, int mode, hipStream_t s);

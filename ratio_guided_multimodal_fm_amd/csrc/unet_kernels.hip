@@ -329,6 +329,7 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const TimeEmbedArgs a) 
     const float arg = t * a.freqs[tid];
     s_emb[tid] = cosf(arg);
     s_emb[half + tid] = sinf(arg);
+    if (a.emb_out) a.emb_out[(size_t)i * a.mc + tid] = s_emb[tid], a.emb_out[(size_t)i * a.mc + half + tid] = s_emb[half + tid];
   }
   __syncthreads();
   const float* P = a.params;

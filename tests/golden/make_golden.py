@@ -369,6 +369,44 @@ def gen_coherence():
          num_samples=res["num_samples"])
 
 
+def gen_sweep200():
+    """BASELINE configs[4] in miniature: the reference's guidance-strength sweep (evaluate_mnist_svhn.py:130-183) at
+    its 200 Euler steps -- methods x strengths in the reference's loop order, `none` with gamma > 0 skipped, ONE
+    seeding before the sweep (:80) and no re-seed between configurations, so configuration i integrates the i-th
+    set of draws (x0, y0[, mc_x0, mc_y0]) of one generator stream -- followed by the two classifiers and
+    evaluate_coherence on each configuration's samples.  The reference builds a fresh ratio estimator per
+    configuration (:141-151); on its own default device ('cuda') that does not touch the generator the noise is
+    drawn from, so here the estimator is built before the stream is seeded."""
+    from ratio_guided_multimodal_fm_amd.models import svhn_classifier as our_clf
+    rm = build(RefUNetMNIST, ours.FlowMatchingUNetMNIST, SEED_W["mnist32"], 32)
+    rs = build(RefUNetSVHN, ours.FlowMatchingUNetSVHN, SEED_W["svhn"])
+    rr = build(RefRatioMS, ours.RatioEstimatorMNISTSVHN, SEED_W["ratio_ms"])
+    cm = build(RefMNISTClf, our_clf.MNISTClassifier32, SEED_W["clf_mnist"])
+    cs = build(RefSVHNClf, our_clf.SVHNClassifier, SEED_W["clf_svhn"])
+    B, N, S, seed = 3, 6, 200, 50
+    methods, strengths = ["none", "mc_feng"], [0.0, 0.5, 1.0, 2.0, 5.0]
+    out = {"cfg": np.array([B, N, S, seed]), "strengths": np.array(strengths)}
+    torch.manual_seed(seed)
+    ci = 0
+    for method in methods:
+        for gamma in strengths:
+            if method == "none" and gamma > 0:
+                continue
+            xs, ys = quiet(ref_sample_ms, rm, rs, rr if method != "none" else None, method, gamma, B, S, 'cpu', N)
+            with torch.no_grad():
+                lm, ls = cm(xs), cs(ys)
+            res = ref_evaluate_coherence(xs, ys, cm, cs, 'cpu')
+            out[f"c{ci}_guided"] = np.array(method == "mc_feng")
+            out[f"c{ci}_gamma"] = np.array(gamma)
+            out[f"c{ci}_x"], out[f"c{ci}_y"] = n(xs), n(ys)
+            out[f"c{ci}_logits_mnist"], out[f"c{ci}_logits_svhn"] = n(lm), n(ls)
+            out[f"c{ci}_coherence_acc"] = np.array(res["coherence_acc"])
+            print(f"  sweep200 c{ci}: {method} gamma={gamma} coherence={res['coherence_acc']:.3f}", flush=True)
+            ci += 1
+    out["n_cfg"] = np.array(ci)
+    save("sweep200", **out)
+
+
 def gen_coherence28():
     """MNISTClassifier (src/models/classifier.py) logits on the golden 28x28 pairs.  src/evaluate.py itself
     cannot be imported here (it needs torchvision), so the coherence value is its :84-91 restated on the
@@ -412,8 +450,9 @@ def gen_fm_original():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["embedding", "unet_layers", "ratio", "guidance", "samplers", "coherence", "fm_original", "coherence28", "fp64", "unet_generic"]
+    which = sys.argv[1:] or ["embedding", "unet_layers", "ratio", "guidance", "samplers", "coherence", "fm_original", "coherence28", "fp64", "unet_generic", "sweep200"]
     for w in which:
         {"embedding": gen_embedding, "unet_layers": gen_unet_layers, "ratio": gen_ratio,
          "guidance": gen_guidance, "samplers": gen_samplers, "coherence": gen_coherence,
-         "fm_original": gen_fm_original, "coherence28": gen_coherence28, "fp64": gen_fp64, "unet_generic": gen_unet_generic}[w]()
+         "fm_original": gen_fm_original, "coherence28": gen_coherence28, "fp64": gen_fp64, "unet_generic": gen_unet_generic,
+         "sweep200": gen_sweep200}[w]()

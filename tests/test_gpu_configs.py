@@ -1,0 +1,225 @@
+"""GPU tests of the BASELINE configurations the one-GPU box can cover beyond tests/test_gpu_parity.py:
+
+* configs[4] in miniature -- the reference's guidance-strength sweep at 200 Euler steps driven through
+  ``evaluate_mnist_svhn.run_sweep`` on the real HIP sampler, against a reference-generated fixture
+  (tests/golden/sweep200.npz: samples, classifier logits and coherence per configuration);
+* configs[3]'s per-rank shape -- gamma 1.0, 512 rows, N_mc 256, all 100 steps -- through
+  ``sharded_paired_sampler`` under a one-rank RCCL group, rows compared with the CPU oracle over the whole
+  trajectory including the stiff last steps (t >= 0.9);
+* the checkpoint boundary: both on-disk formats through ``load_checkpoint`` and the CLIs
+  ``sample_mnist_svhn.main`` / ``evaluate_mnist_svhn.main`` / ``sample.main`` end to end from checkpoint files;
+* the time-embedding table against the reference's ``timestep_embedding`` fixture (a7).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from helpers import golden, make_module, maxdiff, oracle_net, paired_noise
+from ratio_guided_multimodal_fm_amd import _engine, _lib
+
+pytestmark = pytest.mark.gpu
+
+TOL_SAMPLER = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def test_sweep_200_steps_on_the_hip_sampler(dev):
+    """evaluate_mnist_svhn.run_sweep (methods x strengths, skip rule, one seeding, no re-seed) with the real HIP
+    sampler at 200 steps: samples 1e-4, the classifiers' logits on them, coherence per configuration."""
+    from ratio_guided_multimodal_fm_amd.evaluate_mnist_svhn import run_sweep
+    from ratio_guided_multimodal_fm_amd.sample_mnist_svhn import sample_bimodal_guided_mnist_svhn  # noqa: F401
+    from ratio_guided_multimodal_fm_amd.utils.flow_utils import paired_sampler
+    g = golden("sweep200")
+    B, N, S, seed = (int(v) for v in g["cfg"])
+    fm, fs, rr = make_module("mnist32", dev), make_module("svhn", dev), make_module("ratio_ms", dev)
+    cm, cs = make_module("clf_mnist", dev), make_module("clf_svhn", dev)
+    produced = []
+
+    def sampler(fm_m, fm_s, ratio, method, strength, n, steps, device, mc):
+        # the reference draws x0, y0[, mc_x0, mc_y0] from ONE generator stream seeded once before the sweep
+        # (evaluate_mnist_svhn.py:80); the fixture was produced on the torch CPU generator, so the draws are
+        # made there, in the reference's order, and uploaded
+        guided = method == "mc_feng" and ratio is not None
+        x0 = torch.randn(n, 1, 32, 32)
+        y0 = torch.randn(n, 3, 32, 32)
+        mx = torch.randn(mc, 1, 32, 32) if guided else None
+        my = torch.randn(mc, 3, 32, 32) if guided else None
+        xs, ys = paired_sampler(fm_m, fm_s, ratio, method, strength, n, steps, device, mc, (1, 32, 32), (3, 32, 32),
+                                noise=(x0, y0, mx, my), verbose=False)
+        produced.append((xs, ys))
+        return xs, ys
+
+    torch.manual_seed(seed)
+    res = run_sweep(fm, fs, lambda: rr, cm, cs, ["none", "mc_feng"], [float(v) for v in g["strengths"]], B, S, dev, N,
+                    sampler=sampler)
+    assert len(res) == int(g["n_cfg"]) == len(produced)
+    for ci, (r, (xs, ys)) in enumerate(zip(res, produced)):
+        assert (r["method"] == "mc_feng") == bool(g[f"c{ci}_guided"]) and r["guidance_strength"] == float(g[f"c{ci}_gamma"])
+        assert maxdiff(xs.cpu().numpy(), g[f"c{ci}_x"]) < TOL_SAMPLER, ci
+        assert maxdiff(ys.cpu().numpy(), g[f"c{ci}_y"]) < TOL_SAMPLER, ci
+        with torch.no_grad():
+            lm, ls = cm(xs).cpu().numpy(), cs(ys).cpu().numpy()
+            # classifiers themselves: 1e-5 on the reference's own samples
+            assert maxdiff(cm(torch.from_numpy(g[f"c{ci}_x"]).to(dev)).cpu().numpy(), g[f"c{ci}_logits_mnist"]) < 1e-5
+            assert maxdiff(cs(torch.from_numpy(g[f"c{ci}_y"]).to(dev)).cpu().numpy(), g[f"c{ci}_logits_svhn"]) < 1e-5
+        # logits on the HIP samples: the samples differ by <= 1e-4, the classifiers amplify that a little
+        assert maxdiff(lm, g[f"c{ci}_logits_mnist"]) < 2e-3 and maxdiff(ls, g[f"c{ci}_logits_svhn"]) < 2e-3
+        assert np.array_equal(lm.argmax(1), g[f"c{ci}_logits_mnist"].argmax(1))
+        assert np.array_equal(ls.argmax(1), g[f"c{ci}_logits_svhn"].argmax(1))
+        assert abs(r["coherence_acc"] - float(g[f"c{ci}_coherence_acc"])) < 1e-7 and r["num_samples"] == B
+
+
+def test_config3_rank_shape_through_sharded_sampler(dev):
+    """BASELINE configs[3] as one rank sees it at 8 GPUs: gamma 1.0, 512 rows, N_mc 256, ALL 100 steps, through
+    sharded_paired_sampler with the RCCL collectives (one-rank group).  Eight rows (first / middle / last) are
+    followed by the CPU oracle over the whole trajectory -- including t >= 0.9, where sigma_t^2 ~ 1e-4..1e-2
+    makes the importance weights near one-hot -- from the same MC set."""
+    import torch.distributed as dist
+    from ratio_guided_multimodal_fm_amd.distributed import sharded_paired_sampler
+    fm, fs, rr = make_module("mnist32", dev), make_module("svhn", dev), make_module("ratio_ms", dev)
+    B, N, S, gamma = 512, 256, 100, 1.0
+    noise = paired_noise(12, B, N, (1, 32, 32), (3, 32, 32))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29573")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        xs, ys = sharded_paired_sampler(fm, fs, rr, "mc_feng", gamma, S, noise, dev, gather="rank0")
+    finally:
+        dist.destroy_process_group()
+    assert torch.isfinite(xs).all() and torch.isfinite(ys).all()
+    # the MC set the sampler used (deterministic: same calls on the same noise)
+    mx1, my1 = noise[2].to(dev, copy=True), noise[3].to(dev, copy=True)
+    _engine.sample_two_streams(fm, mx1, fs, my1, S)
+    r = rr._engine.eval(mx1, my1, "ratio")
+    dx, bx = oracle_net("mnist32")
+    dy, by = oracle_net("svhn")
+    rows = [0, 1, 127, 255, 256, 383, 510, 511]
+    x0, y0 = noise[0][rows].numpy(), noise[1][rows].numpy()
+    mxn, myn, rn = mx1.cpu().numpy(), my1.cpu().numpy(), r.cpu().numpy()
+    # whole trajectory
+    ox, oy = O.sample_pair(dx, bx, dy, by, x0, y0, mxn, myn, rn, S, gamma, 0, S)
+    assert maxdiff(xs[rows].cpu().numpy(), ox) < TOL_SAMPLER
+    assert maxdiff(ys[rows].cpu().numpy(), oy) < TOL_SAMPLER
+    # the last ten steps on their own, started from the oracle's state at t = 0.9: the HIP guidance at
+    # near-one-hot weights, at the benchmark N
+    ox90, oy90 = O.sample_pair(dx, bx, dy, by, x0, y0, mxn, myn, rn, S, gamma, 0, 90)
+    xg, yg = torch.from_numpy(ox90).to(dev), torch.from_numpy(oy90).to(dev)
+    _engine.sample_pair(fm, fs, xg, yg, mx1, my1, r, S, gamma, 90, S)
+    ox2, oy2 = O.sample_pair(dx, bx, dy, by, ox90, oy90, mxn, myn, rn, S, gamma, 90, S)
+    assert maxdiff(xg.cpu().numpy(), ox2) < TOL_SAMPLER and maxdiff(yg.cpu().numpy(), oy2) < TOL_SAMPLER
+
+
+def test_time_embedding_table_against_reference_fixture(dev):
+    """a7: the sinusoidal embedding (cos half first, unscaled t; unet_flexible.py:16-36) as the DEVICE evaluates it
+    in front of the time MLPs (rgfm_unet_time_embedding), against the reference's timestep_embedding fixture, for
+    both model widths (32: MNIST net, 64: SVHN net); plus the host-side mirror of the module API."""
+    from ratio_guided_multimodal_fm_amd.models.unet_flexible import timestep_embedding
+    g = golden("timestep_embedding")
+    t = torch.tensor(g["t"], dtype=torch.float32)
+    for tag, dim in (("mnist32", 32), ("svhn", 64)):
+        ref = g[f"emb{dim}"]
+        assert maxdiff(timestep_embedding(t, dim).numpy(), ref) < 1e-6
+        m = make_module(tag, dev)
+        got = m._engine.time_embedding(t.to(dev)).cpu().numpy()
+        assert got.shape == ref.shape and maxdiff(got, ref) < 2e-6, (tag, maxdiff(got, ref))
+
+
+# ------------------------------------------------------------------ checkpoints and CLIs
+def _write_checkpoints(tmp_path):
+    """The files the reference's trainers write, from synthetic weights: dict format for the two flow nets
+    (train_flow_mnist32.py:137-143, train_flow_svhn.py:164-170), raw state_dict for the ratio estimator and the
+    classifiers (train_ratio_mnist_svhn.py:142-143, train_classifiers_mnist_svhn.py:152-153,172-173)."""
+    ck = tmp_path / "checkpoints"
+    ck.mkdir()
+    fm, fs, rr = make_module("mnist32"), make_module("svhn"), make_module("ratio_ms")
+    cm, cs = make_module("clf_mnist"), make_module("clf_svhn")
+    torch.save({"epoch": 7, "model_state_dict": fm.state_dict(), "optimizer_state_dict": {}, "best_loss": 0.25},
+               ck / "flow_mnist32_best.pth")
+    torch.save({"epoch": 3, "model_state_dict": fs.state_dict(), "optimizer_state_dict": {}, "best_loss": 0.5},
+               ck / "flow_svhn_best.pth")
+    torch.save(rr.state_dict(), ck / "ratio_disc_mnist_svhn_best.pth")
+    torch.save(cm.state_dict(), ck / "mnist32_classifier.pth")
+    torch.save(cs.state_dict(), ck / "svhn_classifier.pth")
+    return fm, fs, rr, cm, cs
+
+
+def test_checkpoint_formats_give_bitwise_equal_forward(dev, tmp_path):
+    from ratio_guided_multimodal_fm_amd import models as M
+    from ratio_guided_multimodal_fm_amd.utils import load_checkpoint
+    fm, fs, rr, _, _ = _write_checkpoints(tmp_path)
+    ck = tmp_path / "checkpoints"
+    raw = tmp_path / "raw.pth"
+    torch.save(fm.state_dict(), raw)  # train_flow.py:101 format
+    x = torch.randn(3, 1, 32, 32, generator=torch.Generator().manual_seed(1)).to(dev)
+    t = torch.tensor([0.2, 0.5, 0.7], device=dev)
+    ref = fm.to(dev)(x, t)
+    a = M.FlowMatchingUNetMNIST(32).to(dev).eval()
+    info = load_checkpoint(a, str(ck / "flow_mnist32_best.pth"), dev)
+    assert info == {"epoch": 7, "best_loss": 0.25}
+    b = M.FlowMatchingUNetMNIST(32).to(dev).eval()
+    assert load_checkpoint(b, str(raw), dev) == {}
+    assert torch.equal(a(x, t), ref) and torch.equal(b(x, t), ref)
+    with pytest.raises(RuntimeError):  # a wrong architecture fails like torch's load_state_dict does
+        load_checkpoint(M.FlowMatchingUNetSVHN().to(dev), str(raw), dev)
+
+
+def test_cli_mains_from_checkpoint_files(dev, tmp_path, monkeypatch):
+    """sample_mnist_svhn.main and evaluate_mnist_svhn.main end to end from checkpoint files (tiny B / steps),
+    outputs compared with the direct API call under the same seed."""
+    import ratio_guided_multimodal_fm_amd as R
+    from ratio_guided_multimodal_fm_amd import evaluate_mnist_svhn, sample_mnist_svhn
+    fm, fs, rr, cm, cs = _write_checkpoints(tmp_path)
+    monkeypatch.chdir(tmp_path)
+    assert sample_mnist_svhn.main(["--guidance_method", "mc_feng", "--guidance_strength", "0.5", "--num_samples", "3",
+                                   "--num_steps", "4", "--mc_batch_size", "5", "--seed", "9"]) == 0
+    saved = torch.load(tmp_path / "outputs" / "mnist_svhn" / "samples_mc_feng_gamma0.5.pt")
+    R.utils.set_seed(9)
+    xs, ys = R.sample_bimodal_guided_mnist_svhn(fm.to(dev), fs.to(dev), rr.to(dev), "mc_feng", 0.5, num_samples=3,
+                                                num_steps=4, device=dev, mc_batch_size=5)
+    assert torch.equal(saved["mnist"], xs.cpu()) and torch.equal(saved["svhn"], ys.cpu())
+    # missing checkpoint: the reference prints an error and returns (sample_mnist_svhn.py:283-291)
+    os.rename(tmp_path / "checkpoints" / "flow_svhn_best.pth", tmp_path / "checkpoints" / "moved.pth")
+    assert sample_mnist_svhn.main(["--num_samples", "2", "--num_steps", "2"]) == 1
+    os.rename(tmp_path / "checkpoints" / "moved.pth", tmp_path / "checkpoints" / "flow_svhn_best.pth")
+
+    assert evaluate_mnist_svhn.main(["--guidance_methods", "none", "mc_feng", "--guidance_strengths", "0.0", "1.0",
+                                     "--num_samples", "4", "--num_steps", "3", "--mc_batch_size", "5", "--seed", "5"]) == 0
+    res = json.load(open(tmp_path / "outputs" / "mnist_svhn" / "evaluation_results.json"))
+    assert [(r["method"], r["guidance_strength"]) for r in res] == [("none", 0.0), ("mc_feng", 0.0), ("mc_feng", 1.0)]
+    R.utils.set_seed(5)
+    want = evaluate_mnist_svhn.run_sweep(fm.to(dev), fs.to(dev), lambda: rr.to(dev), cm.to(dev), cs.to(dev),
+                                         ["none", "mc_feng"], [0.0, 1.0], 4, 3, dev, 5)
+    assert res == want
+
+
+def test_cli_sample28_from_checkpoint_files(dev, tmp_path, monkeypatch):
+    """src/sample.py twin: checkpoint names from get_checkpoint_path, raw state_dict files (train_flow.py:101)."""
+    import ratio_guided_multimodal_fm_amd as R
+    from ratio_guided_multimodal_fm_amd import sample as sample28
+    from ratio_guided_multimodal_fm_amd.utils.path_utils import get_checkpoint_path
+    monkeypatch.chdir(tmp_path)
+    fx, fy, rr = make_module("unet28"), make_module("unet28_y"), make_module("ratio28")
+    torch.save(fx.state_dict(), get_checkpoint_path("flow", "x", None, "best"))
+    torch.save(fy.state_dict(), get_checkpoint_path("flow", "y", "rotate90", "best"))
+    torch.save(rr.state_dict(), get_checkpoint_path("ratio", "disc", "rotate90", "best"))
+    rc = sample28.main(["--guidance_method", "mc_feng", "--guidance_strength", "0.5", "--num_samples", "3", "--num_steps", "3",
+                        "--mc_batch_size", "4", "--seed", "3"])
+    assert rc == 0
+    outs = list((tmp_path / "outputs").rglob("*.pt"))
+    assert len(outs) == 1
+    saved = torch.load(outs[0])
+    R.utils.set_seed(3)
+    xs, ys = R.sample_bimodal_guided(fx.to(dev), fy.to(dev), rr.to(dev), "mc_feng", 0.5, num_samples=3, num_steps=3,
+                                     device=dev, mc_batch_size=4)
+    vals = list(saved.values())
+    assert torch.equal(vals[0], xs.cpu()) and torch.equal(vals[1], ys.cpu())
