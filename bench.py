@@ -15,15 +15,19 @@ on noise that is already resident in HBM.  Synthetic parameters
 CPU-generator noise seeded 42 (the reference CLI's default seed).
 
 Rank 0 prints ONE JSON line with the driver's contract fields plus
-  roofline     : the conv kernel class, hipEvent-timed on the launch streams inside the
-                 timed region (librgfm_hip's rgfm_profile_*).  Default arithmetic (RGFM_CONV
-                 unset / bx3): fp32 operands split exactly into three bf16 planes, six
-                 bf16-MFMA products per fp32 product, fp32 accumulate -> peak = dense bf16
-                 peak / 6 in fp32-equivalent TFLOP/s.  RGFM_CONV=f32: v_mfma_f32_32x32x2_f32,
-                 peak 157.3.  At N=1 one extra (untimed-for-`value`) call in the other mode is
-                 reported as roofline.exact_fp32_mode.
+  roofline     : the conv kernel class (the dominant kernels, matrix-core-bound), hipEvent-timed on the
+                 launch streams inside the timed region (librgfm_hip's rgfm_profile_*).  Default arithmetic
+                 (RGFM_CONV unset / hx2): fp32 operands as two scaled fp16 planes, three f16-MFMA products per
+                 fp32 product, fp32 accumulate -> peak = dense f16 MFMA peak / 3 in fp32-equivalent TFLOP/s
+                 (`peak` = `peak_nominal`: the guide's 2500 TFLOP/s; `peak_sustained`: the rate a register-only
+                 MFMA loop holds on THIS device under DVFS, measured in this process after the timed region).
+                 RGFM_CONV=bx3: three bf16 planes, six products (peak / 6); RGFM_CONV=f32: v_mfma_f32_32x32x2_f32,
+                 peak 157.3.  At N=1 one extra (untimed-for-`value`) call in exact-fp32 mode is reported as
+                 roofline.exact_fp32_mode.  roofline.hbm_kernels: the HBM-bound kernels of a step (guidance,
+                 first / last conv of each net) with their algorithmic GB/s against the nominal 8 TB/s and
+                 against a float4 copy measured in this process.
   cpu_baseline : the CPU oracle (a C port of the reference algorithm, test
-                 infrastructure) timed on this host's cores on a bounded sample.
+                 infrastructure) timed on this host's cores on a bounded sample (N=1 only).
 """
 import argparse
 import json
@@ -38,8 +42,11 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
-BX3_PRODUCTS = 6                # bf16 MFMA products per fp32 multiply-add in conv_mfma_bx3.hip
+PEAK_16BIT_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / f16 MFMA
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured with a float4 copy)
+PRODUCTS = {"hx2": 3, "bx3": 6}  # 16-bit MFMA products per fp32 multiply-add (conv_mfma_hx2*.hip, conv_mfma_bx3.hip)
+KCLASS = {"conv": 0, "other": 1, "conv_in<1>": 2, "conv_in<3>": 3, "conv_out<1>": 4, "conv_out<3>": 5,
+          "guid_logp": 6, "guid_apply": 7}  # include/rgfm.h RGFM_KCLASS_*
 
 
 def parse():
@@ -56,6 +63,9 @@ def parse():
                    help="skip the hipEvent kernel-class timers (use under rocprofv3)")
     p.add_argument("--no-alt-mode", action="store_true",
                    help="skip the extra call in exact-fp32-MFMA mode (reported beside the default mode)")
+    p.add_argument("--no-arith-check", action="store_true",
+                   help="skip the small float64 error check after the timed region (use under rocprofv3: the trace "
+                        "then ends with the guided main loop)")
     return p.parse_args()
 
 
@@ -64,7 +74,9 @@ def cpu_baseline(fm, fs, rr, euler_steps, B_full, N_full):
     from oracle import oracle as O
     from ratio_guided_multimodal_fm_amd.synth import paired_noise
     cores = O.num_threads()
-    B, N, S = max(16, cores), max(8, cores // 2), 12  # one row per core: the oracle threads over rows
+    # one row per core (the oracle threads over rows), the workload's own N_mc; the number
+    # of Euler steps is what bounds the sample to ~10-30 s
+    B, N, S = max(16, cores), N_full, 6
     noise = tuple(v.numpy() for v in paired_noise(42, B, N, (1, 32, 32), (3, 32, 32)))
     dx, bx, dy, by, br = O.desc_of(fm), O.blob_of(fm), O.desc_of(fs), O.blob_of(fs), O.blob_of(rr)
     t0 = time.perf_counter()
@@ -86,6 +98,18 @@ def cpu_baseline(fm, fs, rr, euler_steps, B_full, N_full):
     }
 
 
+def kernel_sources_sha():
+    """sha256 over the conv kernel sources: ties a committed PMC traffic file to the code it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "ratio_guided_multimodal_fm_amd", "csrc")
+    for name in ("conv_hx2_common.h", "conv_mfma_hx2.hip", "conv_mfma_hx2p.hip", "conv_mfma_bx3.hip", "conv_mfma.hip",
+                 "rgfm_device.h", "rgfm_kernels.h"):
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,7 +124,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from ratio_guided_multimodal_fm_amd import _engine, models as M
+    from ratio_guided_multimodal_fm_amd import _engine, _lib, models as M
     from ratio_guided_multimodal_fm_amd.distributed import sharded_paired_sampler
     from ratio_guided_multimodal_fm_amd.synth import load_synth, paired_noise
 
@@ -129,11 +153,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        one_call(i)
     timers = not args.no_kernel_timers
+    if args.warmup == 0 and timers:
+        raise SystemExit("the kernel timers need one warm-up call to size their event pool: use --warmup >= 1")
+    for i in range(args.warmup):
+        if timers and i == args.warmup - 1:
+            _engine.profile(enable=True, reset=True)  # count the launches of one call ...
+        one_call(i)
     fence()
     if timers:
+        per_call = sum(_engine.profile_read(k)[2] for k in KCLASS.values())
+        _engine.profile(enable=False)
+        # ... and create every hipEvent the timed region will record BEFORE it starts
+        _engine.profile(reserve=int(per_call * (args.steps + 2) * 1.05) + 64)
         _engine.profile(enable=True, reset=True)
     t0 = time.perf_counter()
     for i in range(args.warmup, calls):
@@ -141,17 +173,21 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     conv_ms = conv_sum_ms = conv_n = conv_fl = 0.0
+    hbm_classes = {}
     if timers:
         conv_ms, conv_sum_ms, conv_n, conv_fl = _engine.profile_read(0)
+        for name, k in KCLASS.items():
+            if k >= 2:
+                hbm_classes[name] = _engine.profile_read(k)
         _engine.profile(enable=False)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     conv_mode_env = os.environ.get("RGFM_CONV")
-    conv_mode = conv_mode_env or "bx3"
+    conv_mode = conv_mode_env or "hx2"
     alt = None
-    if rank == 0 and world == 1 and timers and conv_mode == "bx3" and not args.no_alt_mode:
+    if rank == 0 and world == 1 and timers and conv_mode != "f32" and not args.no_alt_mode:
         # the same call once more with the exact-fp32 MFMA conv (the switch is read per launch)
         os.environ["RGFM_CONV"] = "f32"
         one_call(calls - 1)
@@ -163,16 +199,19 @@ def main():
         alt_elapsed = time.perf_counter() - ta
         a_ms, _, a_n, a_fl = _engine.profile_read(0)
         _engine.profile(enable=False)
-        os.environ["RGFM_CONV"] = conv_mode
+        if conv_mode_env is None:
+            os.environ.pop("RGFM_CONV", None)
+        else:
+            os.environ["RGFM_CONV"] = conv_mode_env
         ach_a = a_fl / (a_ms * 1e-3) / 1e12
         alt = {"conv": "v_mfma_f32_32x32x2_f32 (RGFM_CONV=f32)", "value": B / alt_elapsed, "unit": "paired images/sec",
                "achieved": ach_a, "peak": PEAK_FP32_MFMA_TFLOPS, "frac": ach_a / PEAK_FP32_MFMA_TFLOPS, "calls": 1}
 
     arith = None
     gpath = os.path.join(ROOT, "tests", "golden", "fp64_eval.npz")
-    if rank == 0 and world == 1 and os.path.exists(gpath):
+    if rank == 0 and world == 1 and os.path.exists(gpath) and not args.no_arith_check:
         # error of one SVHN-net evaluation against the reference evaluated in float64 (committed golden vector,
-        # tests/golden/make_golden.py) in both conv arithmetic modes: the split-bf16 default is fp32-class
+        # tests/golden/make_golden.py) in every conv arithmetic mode: the split-operand paths are fp32-class
         import numpy as np
         from ratio_guided_multimodal_fm_amd.synth import load_synth as _ls
         g = np.load(gpath)
@@ -180,16 +219,29 @@ def main():
         xg = torch.randn(4, 3, 32, 32, generator=torch.Generator().manual_seed(91)).to(dev)
         tg = torch.tensor([0.05, 0.37, 0.71, 0.99], device=dev)
         errs = {}
-        for mode in ("bx3", "f32"):
+        fb0 = _engine.range_fallbacks
+        for mode in ("hx2", "bx3", "f32"):
             os.environ["RGFM_CONV"] = mode
             errs[mode] = float(np.abs(net(xg, tg).cpu().numpy().astype(np.float64) - g["svhn_f64"]).max())
+        assert _engine.range_fallbacks == fb0  # the fp16 path itself produced errs["hx2"]
         if conv_mode_env is None:
             os.environ.pop("RGFM_CONV", None)
         else:
             os.environ["RGFM_CONV"] = conv_mode_env
         arith = {"what": "max |error| of one SVHN U-Net evaluation (B=4) against the reference run in float64",
-                 "split_bf16_default": errs["bx3"], "exact_fp32_mfma": errs["f32"],
+                 "split_fp16x2_default": errs["hx2"], "split_bf16x3": errs["bx3"], "exact_fp32_mfma": errs["f32"],
                  "reference_own_fp32": float(g["svhn_ref32_err"])}
+
+    ceilings = None
+    if rank == 0 and world == 1 and timers:
+        # measured ceilings of THIS device, after the timed region: what a register-only f16 MFMA loop sustains
+        # under DVFS (the nominal 2500 TFLOP/s assumes 2.4 GHz) and what a float4 copy moves through HBM
+        import ctypes
+        L = _lib.lib()
+        tf, gb = ctypes.c_double(), ctypes.c_double()
+        _lib.check(L.rgfm_ubench_mfma_f16(ctypes.byref(tf)))
+        _lib.check(L.rgfm_ubench_hbm_copy(1 << 30, ctypes.byref(gb)))
+        ceilings = {"mfma_f16_tflops": tf.value, "hbm_copy_gbs": gb.value}
 
     if rank == 0:
         assert out[0] is not None and out[0].shape[0] == B and torch.isfinite(out[0]).all()
@@ -218,34 +270,70 @@ def main():
         }
         if timers and conv_ms > 0:
             ach = conv_fl / (conv_ms * 1e-3) / 1e12
-            # HBM bytes per conv launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
-            # separate runs, gfx950 corrections applied by tools/pmc_traffic.py); bench.py cannot collect PMC itself
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic_bx3.json" if conv_mode == "bx3" else "r01_conv_traffic.json")
-            if os.path.exists(tpath) and args.batch_per_gpu == 512:
-                with open(tpath) as f:
-                    traffic = json.load(f).get("per_launch_avg_bytes")
-            if conv_mode == "bx3":
-                peak = PEAK_BF16_MFMA_TFLOPS / BX3_PRODUCTS
-                kern = ("conv_mfma_bx3w_kernel (implicit-GEMM conv; fp32 operands as 3 exact bf16 planes, 6 bf16-MFMA "
-                        "products per fp32 product, fp32 accumulate; stride-2 convs on conv_mfma_kernel)")
-                basis = (f"fp32-equivalent: {PEAK_BF16_MFMA_TFLOPS:.0f} TFLOP/s dense bf16 MFMA / {BX3_PRODUCTS} products; "
+            if conv_mode in PRODUCTS:
+                npr = PRODUCTS[conv_mode]
+                peak = PEAK_16BIT_MFMA_TFLOPS / npr
+                if conv_mode == "hx2":
+                    kern = ("conv_mfma_hx2p_kernel / conv_mfma_hx2_kernel (implicit-GEMM conv; fp32 operands as 2 scaled fp16 "
+                            "planes, 3 f16-MFMA products per fp32 product, fp32 accumulate)")
+                else:
+                    kern = ("conv_mfma_bx3w_kernel (implicit-GEMM conv; fp32 operands as 3 exact bf16 planes, 6 bf16-MFMA "
+                            "products per fp32 product, fp32 accumulate)")
+                basis = (f"fp32-equivalent: {PEAK_16BIT_MFMA_TFLOPS:.0f} TFLOP/s dense 16-bit MFMA / {npr} products; "
                          "achieved counts algorithmic conv FLOPs (2*MAC) once")
+                sustained = ceilings["mfma_f16_tflops"] / npr if ceilings else None
             else:
                 peak = PEAK_FP32_MFMA_TFLOPS
                 kern = "conv_mfma*_kernel (fp32 MFMA implicit-GEMM conv, all shapes)"
                 basis = "v_mfma_f32_32x32x2_f32 dense peak"
+                sustained = None
+            # HBM bytes per conv launch: bench.py cannot collect PMC itself.  The value comes from the rocprofv3
+            # --pmc passes of tools/pmc_traffic.py (FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 corrections),
+            # committed under profiles/ with the hash of the kernel sources it was taken with; it is reported only
+            # while those sources are unchanged, and the line names the file and its sha256.
+            traffic, traffic_src = None, None
+            tpath = os.path.join(ROOT, "profiles", f"r02_conv_traffic_{conv_mode}.json")
+            if os.path.exists(tpath) and args.batch_per_gpu == 512:
+                import hashlib
+                with open(tpath, "rb") as f:
+                    raw = f.read()
+                tj = json.loads(raw)
+                if tj.get("kernel_sources_sha256") == kernel_sources_sha():
+                    traffic = tj.get("per_launch_avg_bytes")
+                    traffic_src = {"file": os.path.relpath(tpath, ROOT), "sha256": hashlib.sha256(raw).hexdigest()}
+                else:
+                    traffic_src = {"file": os.path.relpath(tpath, ROOT), "stale": "kernel sources changed since the PMC pass"}
             line["roofline"] = {
                 "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                "frac": ach / peak, "traffic": traffic,
+                "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
+                "peak_nominal": peak, "peak_sustained": sustained,
+                "frac_sustained": (ach / sustained) if sustained else None,
                 "kernel": kern, "peak_basis": basis, "conv_arithmetic": conv_mode,
                 "launches": int(conv_n), "avg_launch_us": 1e3 * conv_sum_ms / max(conv_n, 1),
                 "busy_ms": conv_ms, "sum_launch_ms": conv_sum_ms,
-                "timing": "hipEvents on the launch streams over the timed region; achieved = algorithmic FLOPs / "
-                          "UNION of the launches' intervals (the two nets of a step run on two streams, so "
+                "timing": "hipEvents (created before the timed region) on the launch streams; achieved = algorithmic "
+                          "FLOPs / UNION of the launches' intervals (the two nets of a step run on two streams, so "
                           "launches overlap; sum_launch_ms double-counts that time; RGFM_OVERLAP=0 serialises)",
                 "kernel_time_share": conv_ms * 1e-3 / elapsed,
             }
+            if ceilings:
+                line["roofline"]["measured_ceilings"] = {
+                    "mfma_f16_tflops": ceilings["mfma_f16_tflops"], "hbm_copy_gbs": ceilings["hbm_copy_gbs"],
+                    "how": "in this process after the timed region: register-only v_mfma_f32_32x32x16_f16 loop on random "
+                           "operands, 2 waves per SIMD on every CU, 0.25 s (rgfm_ubench_mfma_f16); float4 copy of 1 GiB "
+                           "(rgfm_ubench_hbm_copy, read + written bytes)"}
+            hk = {}
+            for name, (busy, tot, nl, by) in hbm_classes.items():
+                if nl > 0 and tot > 0:
+                    gbs = by / (tot * 1e-3) / 1e9
+                    hk[name] = {"launches": int(nl), "avg_launch_us": 1e3 * tot / nl, "algorithmic_gbs": gbs,
+                                "frac_nominal": gbs / PEAK_HBM_GBS,
+                                "frac_measured_copy": (gbs / ceilings["hbm_copy_gbs"]) if ceilings else None}
+            if hk:
+                line["roofline"]["hbm_kernels"] = {
+                    "what": "HBM-bound kernels of the step: algorithmic bytes (SURVEY 8d: every tensor once) / sum of launch "
+                            "durations; peak 8000 GB/s nominal, and the float4 copy measured above",
+                    "share_of_call": sum(v[1] for v in hbm_classes.values()) * 1e-3 / elapsed, **hk}
             if alt is not None:
                 line["roofline"]["exact_fp32_mode"] = alt
             if arith is not None:

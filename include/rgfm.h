@@ -225,20 +225,35 @@ int rgfm_guidance_apply(const float* x, const float* y, float* vx, float* vy, co
  * Bench support: per-kernel-class device time measured with hipEvents on the
  * launch stream (bench.py's roofline line).  Timing is off by default.
  * ---------------------------------------------------------------------- */
-#define RGFM_KCLASS_CONV_MFMA 0 /* conv3x3/1x1 implicit-GEMM (f32 MFMA)  */
-#define RGFM_KCLASS_OTHER 1     /* everything else                       */
-#define RGFM_KCLASS_COUNT 2
+#define RGFM_KCLASS_CONV_MFMA 0  /* conv3x3/1x1 implicit GEMM on the matrix cores: work = FLOPs (2*MAC)      */
+#define RGFM_KCLASS_OTHER 1      /* everything not listed here (work = 0)                                     */
+/* HBM-bound kernels of the U-Net pair step: work = ALGORITHMIC HBM bytes of the launch */
+#define RGFM_KCLASS_CONV_IN1 2   /* input_conv, 1-channel image (conv_in_kernel<1>)                          */
+#define RGFM_KCLASS_CONV_IN3 3   /* input_conv, 3-channel image (conv_in_kernel<3>)                          */
+#define RGFM_KCLASS_CONV_OUT1 4  /* out_norm + SiLU + out_conv (+ fused Euler), 1 channel                    */
+#define RGFM_KCLASS_CONV_OUT3 5  /* ... 3 channels                                                           */
+#define RGFM_KCLASS_GUID_LOGP 6  /* guidance: squared distances to the MC set (guid_logp_kernel)             */
+#define RGFM_KCLASS_GUID_APPLY 7 /* guidance: weights, weighted velocity, blend, Euler (guid_apply_kernel x2) */
+#define RGFM_KCLASS_COUNT 8
 int rgfm_profile_enable(int enable);
 int rgfm_profile_reset(void);
 /* Waits for the recorded events, then returns for the class, since the last reset:
  *   busy_ms  = length of the UNION of the launches' [start, stop] intervals (the two velocity nets
  *              of a step run on two streams, so launches of one class may overlap in time);
  *   sum_ms   = plain sum of the launch durations (== busy_ms when nothing overlaps);
- *   launches, flops = launch count and algorithmic FLOPs (2*MAC). */
+ *   launches, flops = launch count and the class's algorithmic work (FLOPs or bytes, see RGFM_KCLASS_*). */
 int rgfm_profile_read(int kclass, double* busy_ms, double* sum_ms, int64_t* launches, double* flops);
 
 /* Pre-creates the hipEvents of `launches` timed launches, so that none is created inside a timed region. */
 int rgfm_profile_reserve(int64_t launches);
+
+/* Measured ceilings of the current device, for the roofline line (each call takes ~0.2-0.5 s and synchronises):
+ *   rgfm_ubench_mfma_f16: sustained dense f16 MFMA rate (v_mfma_f32_32x32x16_f16, operands in registers, random
+ *     data, two waves per SIMD on every CU, >= 0.2 s) in TFLOP/s -- what the chip holds under DVFS, as opposed to
+ *     the 2500 TFLOP/s nominal peak;
+ *   rgfm_ubench_hbm_copy: float4 copy of `bytes` (>= 256 MiB recommended) in GB/s of read + written bytes. */
+int rgfm_ubench_mfma_f16(double* tflops);
+int rgfm_ubench_hbm_copy(size_t bytes, double* gbps);
 
 /* Range flag of the default fp16 conv path (see "arithmetic" above): waits for `stream`, then
  * *flagged = 1 if any convolution launched on the current device since the last reset staged an

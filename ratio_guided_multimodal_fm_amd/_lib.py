@@ -78,6 +78,8 @@ SIGNATURES = {
     "rgfm_profile_reset": (c_int, []),
     "rgfm_profile_read": (c_int, [c_int, P(c_double), P(c_double), P(c_int64), P(c_double)]),
     "rgfm_profile_reserve": (c_int, [c_int64]),
+    "rgfm_ubench_mfma_f16": (c_int, [P(c_double)]),
+    "rgfm_ubench_hbm_copy": (c_int, [c_size_t, P(c_double)]),
     "rgfm_range_flag_read": (c_int, [P(c_int), c_int, c_void_p]),
     "rgfm_abi_version": (c_int, []),
     "rgfm_last_error": (ctypes.c_char_p, []),

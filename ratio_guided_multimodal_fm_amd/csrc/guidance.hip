@@ -212,9 +212,12 @@ __global__ __launch_bounds__(256) void guid_apply_kernel(const GuidanceArgs a, i
   }
 }
 
-void launch_guidance(const GuidanceArgs& a, hipStream_t s) {
+void launch_guid_logp(const GuidanceArgs& a, hipStream_t s) {
   dim3 g1((a.B + 31) / 32, (a.N + 31) / 32, a.nsx + a.nsy);
   hipLaunchKernelGGL(guid_logp_kernel, g1, dim3(256), 0, s, a);
+}
+
+void launch_guid_apply(const GuidanceArgs& a, hipStream_t s) {
   const size_t lds = (size_t)4 * a.N * sizeof(float);
   hipLaunchKernelGGL(guid_apply_kernel, dim3((a.B + 3) / 4, (a.dx + 1023) / 1024), dim3(256), lds, s, a, 0);
   hipLaunchKernelGGL(guid_apply_kernel, dim3((a.B + 3) / 4, (a.dy + 1023) / 1024), dim3(256), lds, s, a, 1);

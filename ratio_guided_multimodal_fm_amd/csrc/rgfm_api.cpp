@@ -49,9 +49,9 @@ struct Prof {
   std::vector<hipEvent_t> ev;  // pairs
   std::vector<int> cls;
   size_t used = 0;
-  double flops[RGFM_KCLASS_COUNT] = {0, 0};
-  double sum_ms[RGFM_KCLASS_COUNT] = {0, 0};
-  int64_t launches[RGFM_KCLASS_COUNT] = {0, 0};
+  double flops[RGFM_KCLASS_COUNT] = {};  // algorithmic FLOPs (conv class) or algorithmic HBM bytes (the others)
+  double sum_ms[RGFM_KCLASS_COUNT] = {};
+  int64_t launches[RGFM_KCLASS_COUNT] = {};
   std::vector<std::pair<double, double>> iv[RGFM_KCLASS_COUNT];  // [start, stop] ms since the first event
   hipEvent_t base = nullptr;
   bool have_base = false;
@@ -627,7 +627,10 @@ struct UNetRun {
       ConvInArgs ci{};
       ci.x = x, ci.w = h->params + h->icw, ci.bias = h->params + h->icb;
       ci.out = cur.data, ci.stats_out = cur.stats, ci.B = B, ci.C0 = h->mc, ci.g = make_geom(S, S);
-      ProfScope p(RGFM_KCLASS_OTHER, 0, s);
+      // algorithmic bytes: the NCHW image in, the NHWC map (+ its statistics) out
+      const TileGeom g0 = make_geom(S, S);
+      ProfScope p(d.in_channels == 1 ? RGFM_KCLASS_CONV_IN1 : RGFM_KCLASS_CONV_IN3,
+                  4.0 * B * ((double)S * S * (d.in_channels + h->mc) + 2.0 * g0.nparts * h->mc), s);
       launch_conv_in(ci, d.in_channels, s);
     }
     record(cur);
@@ -666,7 +669,10 @@ struct UNetRun {
       co.v_out = v_out, co.x_state = x_state, co.dt = dt, co.B = B, co.Cin = cur.C;
       co.g = make_geom(cur.S, cur.S);
       co.halo_px = co.g.spt * (co.g.th + 2) * (co.g.W + 2);
-      ProfScope p(RGFM_KCLASS_OTHER, 0, s);
+      // algorithmic bytes: the NHWC map + its scale/shift in, the NCHW velocity out (fused Euler: state in and out)
+      const double px = (double)B * cur.S * cur.S;
+      ProfScope p(d.in_channels == 1 ? RGFM_KCLASS_CONV_OUT1 : RGFM_KCLASS_CONV_OUT3,
+                  4.0 * (px * cur.C + 2.0 * B * cur.C + px * d.in_channels * ((v_out ? 1 : 0) + (x_state ? 2 : 0))), s);
       launch_conv_out(co, d.in_channels, s);
       if (h->trace && v_out) h->acts.push_back({v_out, d.in_channels, cur.S, true});
     }
@@ -967,8 +973,17 @@ int guidance_launch(const float* x, const float* y, float* vx, float* vy, const 
   a.slice_len = 1024;  // 1024-element slices unless that needs more than RGFM_GUID_SLICES of them
   while ((dx + a.slice_len - 1) / a.slice_len + (dy + a.slice_len - 1) / a.slice_len > RGFM_GUID_SLICES) a.slice_len *= 2;
   a.nsx = (dx + a.slice_len - 1) / a.slice_len, a.nsy = (dy + a.slice_len - 1) / a.slice_len;
-  ProfScope p(RGFM_KCLASS_OTHER, 0, s);
-  launch_guidance(a, s);
+  // algorithmic bytes.  logp: rows of x, y and the MC set in, the sliced fp64 distances out.  apply: the
+  // distances, x, y, v and the MC set in, the new state (or velocity) out.
+  const double D = (double)dx + dy, dist_b = 8.0 * (a.nsx + a.nsy) * (double)B * N;
+  {
+    ProfScope p(RGFM_KCLASS_GUID_LOGP, 4.0 * (B + N) * D + dist_b, s);
+    launch_guid_logp(a, s);
+  }
+  {
+    ProfScope p(RGFM_KCLASS_GUID_APPLY, dist_b + 4.0 * N * D + 4.0 * B * D * 3.0, s);
+    launch_guid_apply(a, s);
+  }
   return RGFM_OK;
 }
 }  // namespace

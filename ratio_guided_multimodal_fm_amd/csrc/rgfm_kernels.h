@@ -263,7 +263,8 @@ struct GuidanceArgs {
   float dt;
 };
 constexpr int RGFM_GUID_SLICES = 8;
-void launch_guidance(const GuidanceArgs& a, hipStream_t s);
+void launch_guid_logp(const GuidanceArgs& a, hipStream_t s);   // distances -> GuidanceArgs::dist
+void launch_guid_apply(const GuidanceArgs& a, hipStream_t s);  // weights, guided velocity, blend (+ Euler)
 void launch_euler(float* x, const float* v, size_t n, float dt, hipStream_t s);
 
 }  // namespace rgfm

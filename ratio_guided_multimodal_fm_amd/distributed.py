@@ -130,3 +130,46 @@ def _gather_rows(t, counts, group, rank, dst=0):
     if rank != dst:
         return None
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0)
+
+
+def init_from_env(backend="nccl"):
+    """Process-group setup of a `torch.distributed.run` launch (one process per GPU):
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment, RCCL over xGMI.  Returns (rank, world, device).
+    A plain `python` launch (no WORLD_SIZE) is rank 0 of 1 with no process group."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+    else:
+        device = torch.device("cpu")
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, device
+
+
+def make_sharded_sampler(shape_x, shape_y, backend=None, group=None, gather="all"):
+    """A drop-in for ``sample_bimodal_guided*`` (same positional signature) that shards the rows over the ranks.
+
+    The reference draws x0, y0[, mc_x0, mc_y0] from the target device's global generator
+    (sample_mnist_svhn.py:74,75,89,98).  Ranks must integrate rows of ONE noise set, so here every rank draws
+    the FULL tensors from its torch CPU generator in that order -- seed all ranks alike (``set_seed``), as the
+    launchers do -- and ``sharded_paired_sampler`` slices its rows: consecutive calls consume one generator
+    stream exactly like the reference's sweep (evaluate_mnist_svhn.py:80: one seeding, no re-seed)."""
+    def sampler(fm_x, fm_y, ratio_estimator=None, guidance_method='none', guidance_strength=0.0, num_samples=16,
+                num_steps=100, device='cuda', mc_batch_size=64):
+        guided = guidance_method == 'mc_feng' and ratio_estimator is not None
+        x0 = torch.randn(num_samples, *shape_x)
+        y0 = torch.randn(num_samples, *shape_y)
+        mx = torch.randn(mc_batch_size, *shape_x) if guided else None
+        my = torch.randn(mc_batch_size, *shape_y) if guided else None
+        return sharded_paired_sampler(fm_x, fm_y, ratio_estimator, guidance_method, guidance_strength, num_steps,
+                                      (x0, y0, mx, my), torch.device(device), backend=backend, group=group, gather=gather)
+    return sampler

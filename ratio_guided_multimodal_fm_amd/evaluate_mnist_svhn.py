@@ -5,6 +5,17 @@ reference's flags, skip rule (``none`` with gamma > 0), single ``set_seed`` befo
 configuration's noise depends on sweep order, as in the reference) and JSON schema
 (``method, guidance_strength, experiment, coherence_acc, num_samples``).  Sampling runs on the HIP
 path; the two classifiers run once per configuration in PyTorch-ROCm.
+
+Multi-GPU (new; the reference is single-device): launched under ``torch.distributed.run`` with ``--sharded``,
+e.g. BASELINE configs[4]
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        -m ratio_guided_multimodal_fm_amd.evaluate_mnist_svhn --sharded --num_samples 8192 --num_steps 200 \
+        --guidance_strengths 0 0.5 1 2 5
+
+every rank loads the checkpoints, integrates its rows of each configuration (distributed.py: sharded MC
+pre-phase, one RCCL all_gather of the MC set, one all_gather of the outputs) and rank 0 classifies and writes
+the JSON.
 """
 import argparse
 import json
@@ -60,12 +71,21 @@ def main(argv=None):
     p.add_argument('--num_steps', type=int, default=100)
     p.add_argument('--device', type=str, default='cuda')
     p.add_argument('--seed', type=int, default=42)
+    p.add_argument('--sharded', action='store_true',
+                   help='rows sharded over the ranks of a torch.distributed.run launch (one process per GPU, RCCL)')
     args = p.parse_args(argv)
 
-    set_seed(args.seed)
+    set_seed(args.seed)  # (every rank alike: the sharded sampler slices ONE noise set)
     if not torch.cuda.is_available():
         raise RuntimeError("no HIP device visible; the sampler has no CPU path")
-    device = torch.device(args.device)
+    rank, sampler = 0, sample_bimodal_guided_mnist_svhn
+    if args.sharded:
+        from .distributed import init_from_env, make_sharded_sampler
+        rank, world, device = init_from_env("nccl")
+        sampler = make_sharded_sampler((1, 32, 32), (3, 32, 32), gather="all")
+        print(f"rank {rank} of {world} on {device}")
+    else:
+        device = torch.device(args.device)
 
     paths = {'mnist_clf': 'checkpoints/mnist32_classifier.pth', 'svhn_clf': 'checkpoints/svhn_classifier.pth',
              'fm_mnist': 'checkpoints/flow_mnist32_best.pth', 'fm_svhn': 'checkpoints/flow_svhn_best.pth'}
@@ -92,7 +112,15 @@ def main(argv=None):
         return r
 
     results = run_sweep(fm_mnist, fm_svhn, make_ratio, mnist_clf, svhn_clf, args.guidance_methods,
-                        args.guidance_strengths, args.num_samples, args.num_steps, device, args.mc_batch_size)
+                        args.guidance_strengths, args.num_samples, args.num_steps, device, args.mc_batch_size,
+                        sampler=sampler)
+    if args.sharded:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank != 0:
+            return 0
     os.makedirs('outputs/mnist_svhn', exist_ok=True)
     out = 'outputs/mnist_svhn/evaluation_results.json'
     with open(out, 'w') as f:

@@ -34,13 +34,24 @@ def main(argv=None):
     p.add_argument('--num_steps', type=int, default=100)
     p.add_argument('--device', type=str, default='cuda')
     p.add_argument('--seed', type=int, default=42)
+    p.add_argument('--sharded', action='store_true',
+                   help='rows sharded over the ranks of a torch.distributed.run launch (one process per GPU, RCCL); '
+                        'e.g. BASELINE configs[3]: --nproc-per-node 8 ... --sharded --num_samples 4096 '
+                        '--guidance_method mc_feng --guidance_strength 1.0')
     args = p.parse_args(argv)
 
-    set_seed(args.seed)
+    set_seed(args.seed)  # (every rank alike: the sharded sampler slices ONE noise set)
     print(f"Random seed: {args.seed}")
     if not torch.cuda.is_available():
         raise RuntimeError("no HIP device visible; this sampler has no CPU path")
-    device = torch.device(args.device)
+    rank, sampler = 0, sample_bimodal_guided_mnist_svhn
+    if args.sharded:
+        from .distributed import init_from_env, make_sharded_sampler
+        rank, world, device = init_from_env("nccl")
+        sampler = make_sharded_sampler((1, 32, 32), (3, 32, 32), gather="rank0")
+        print(f"rank {rank} of {world}")
+    else:
+        device = torch.device(args.device)
     print(f"Using device: {device}")
 
     fm_mnist = FlowMatchingUNetMNIST(img_size=32).to(device)
@@ -65,9 +76,15 @@ def main(argv=None):
         print(f"  Loaded ratio estimator from: {path}")
 
     print(f"\nSampling {args.num_samples} pairs...")
-    xs, ys = sample_bimodal_guided_mnist_svhn(
-        fm_mnist, fm_svhn, ratio, args.guidance_method, args.guidance_strength, args.num_samples,
-        args.num_steps, device, args.mc_batch_size)
+    xs, ys = sampler(fm_mnist, fm_svhn, ratio, args.guidance_method, args.guidance_strength, args.num_samples,
+                     args.num_steps, device, args.mc_batch_size)
+    if args.sharded:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank != 0:
+            return 0
     os.makedirs('outputs/mnist_svhn', exist_ok=True)
     out = f"outputs/mnist_svhn/samples_{args.guidance_method}_gamma{args.guidance_strength}.pt"
     torch.save({'mnist': xs.cpu(), 'svhn': ys.cpu()}, out)

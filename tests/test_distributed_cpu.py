@@ -84,6 +84,63 @@ def test_sharded_equals_single_process(tmp_path, world, guided):
         assert np.array_equal(g["x"], rx) and np.array_equal(g["y"], ry)
 
 
+def _run_sweep(rank, world, port, out_dir):
+    """The multi-GPU launcher's data path (evaluate_mnist_svhn --sharded) on gloo ranks: run_sweep with the sharded
+    sampler, every rank seeded alike, one generator stream across the configurations."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    os.environ["RANK"], os.environ["WORLD_SIZE"], os.environ["LOCAL_RANK"] = str(rank), str(world), str(rank)
+    import json
+    from helpers import make_module
+    from ratio_guided_multimodal_fm_amd.distributed import init_from_env, make_sharded_sampler
+    from ratio_guided_multimodal_fm_amd.evaluate_mnist_svhn import run_sweep
+    from ratio_guided_multimodal_fm_amd.utils import set_seed
+    r, w, device = init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    fm, fs, rr = make_module("mnist32"), make_module("svhn"), make_module("ratio_ms")
+    cm, cs = make_module("clf_mnist"), make_module("clf_svhn")
+    produced = []
+    inner = make_sharded_sampler((1, 32, 32), (3, 32, 32), backend=OracleBackend(), gather="all")
+
+    def sampler(*a):
+        out = inner(*a)
+        produced.append(out)
+        return out
+
+    set_seed(77)
+    res = run_sweep(fm, fs, lambda: rr, cm, cs, ["none", "mc_feng"], [0.0, 2.0], B, S, device, N, sampler=sampler)
+    np.savez(os.path.join(out_dir, f"sweep_{rank}.npz"), **{f"x{i}": p[0].numpy() for i, p in enumerate(produced)},
+             **{f"y{i}": p[1].numpy() for i, p in enumerate(produced)})
+    with open(os.path.join(out_dir, f"sweep_{rank}.json"), "w") as f:
+        json.dump(res, f)
+    dist.destroy_process_group()
+
+
+def test_sharded_sweep_launcher_path(tmp_path):
+    import json
+    from oracle import oracle as O
+    from helpers import oracle_net
+    world = 2
+    mp.spawn(_run_sweep, args=(world, 29655, str(tmp_path)), nprocs=world, join=True)
+    (dx, bx), (dy, by), (kind, br) = oracle_net("mnist32"), oracle_net("svhn"), oracle_net("ratio_ms")
+    # single-process replay of the same generator stream: configurations (none, 0), (mc_feng, 0), (mc_feng, 2)
+    torch.manual_seed(77)
+    want = []
+    for guided, gamma in ((False, 0.0), (True, 0.0), (True, 2.0)):
+        x0, y0 = torch.randn(B, 1, 32, 32), torch.randn(B, 3, 32, 32)
+        mx = torch.randn(N, 1, 32, 32) if guided else None
+        my = torch.randn(N, 3, 32, 32) if guided else None
+        noise = tuple(None if v is None else v.numpy() for v in (x0, y0, mx, my))
+        want.append(O.paired_sampler(dx, bx, dy, by, kind, br, "disc", noise, guided, gamma, S)[:2])
+    res = [json.load(open(tmp_path / f"sweep_{r}.json")) for r in range(world)]
+    assert res[0] == res[1] and [(r["method"], r["guidance_strength"]) for r in res[0]] == [("none", 0.0), ("mc_feng", 0.0), ("mc_feng", 2.0)]
+    for r in range(world):
+        g = np.load(tmp_path / f"sweep_{r}.npz")
+        for i, (wx, wy) in enumerate(want):
+            assert np.array_equal(g[f"x{i}"], wx) and np.array_equal(g[f"y{i}"], wy)
+
+
 def test_shard_bounds_cover_everything():
     from ratio_guided_multimodal_fm_amd.distributed import shard_bounds
     for n in (0, 1, 7, 256, 4096, 8193):

@@ -2,7 +2,10 @@
 """HBM traffic of the conv_mfma launches from two rocprofv3 --pmc passes
 (FETCH_SIZE, WRITE_SIZE: separate passes, MI355X_MICROARCH.md "HBM").
 
-  tools/pmc_traffic.py <dir_with_FETCH_pass> <dir_with_WRITE_pass> [B] [euler_steps]
+  tools/pmc_traffic.py <dir_with_FETCH_pass> <dir_with_WRITE_pass> [B] > profiles/rNN_conv_traffic_<mode>.json
+
+The output carries the sha256 of the conv kernel sources (bench.kernel_sources_sha): bench.py reports
+`roofline.traffic` from the file only while those sources are unchanged.
 
 Corrections applied as the guide prescribes for gfx950: FETCH_SIZE (KB) under-reports wide
 16-B-per-lane streaming reads by exactly 2x -> doubled; WRITE_SIZE (KB) is exact.
@@ -14,14 +17,19 @@ import json
 import sys
 from collections import defaultdict
 
-sys.path.insert(0, __file__.rsplit("/", 1)[0])
+import os  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
 from trace_layers import unet_convs  # noqa: E402
+from bench import kernel_sources_sha  # noqa: E402
 
 
 def load(d, counter):
     vals = defaultdict(float)
     names = {}
-    for r in csv.DictReader(open(glob.glob(f"{d}/*/*_counter_collection.csv")[0])):
+    for r in csv.DictReader(open(glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True)[0])):
         if r["Counter_Name"] == counter:
             vals[int(r["Dispatch_Id"])] += float(r["Counter_Value"])
             names[int(r["Dispatch_Id"])] = r["Kernel_Name"]
@@ -55,6 +63,7 @@ def main():
         "ratio": (rd + wr) / alg,
         "per_launch_avg_bytes": (rd + wr) / per_step,
         "corrections": "FETCH_SIZE KB x1024 x2 (gfx950 wide-read under-count), WRITE_SIZE KB x1024",
+        "kernel_sources_sha256": kernel_sources_sha(),
     }
     print(json.dumps(out, indent=1))
 
