@@ -143,6 +143,13 @@ int rgfm_ratio_workspace_bytes(const rgfm_ratio* h, int n, size_t* bytes);
 int rgfm_ratio_eval(rgfm_ratio* h, const float* x, const float* y, float* out, int n, int what,
                     void* ws, size_t ws_bytes, rgfm_stream_t stream);
 
+/* Gradient of the log-ratio, d log_ratio(x, y) / d(x, y): what torch.autograd.grad(model.log_ratio(x, y).sum(),
+ * (x, y)) returns for the reference module in eval mode (ratio_flexible.py:347-385; hand-written reverse pass).
+ * gx[n,1,32,32], gy[n,3,32,32]; log_ratio_out (optional) [n].  RGFM_RATIO_MNIST_SVHN only (RGFM_EINVAL otherwise). */
+int rgfm_ratio_grad_workspace_bytes(const rgfm_ratio* h, int n, size_t* bytes);
+int rgfm_ratio_grad_log_ratio(rgfm_ratio* h, const float* x, const float* y, float* gx, float* gy,
+                              float* log_ratio_out, int n, void* ws, size_t ws_bytes, rgfm_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Samplers (the Euler/ODE loops).
  * ---------------------------------------------------------------------- */
@@ -175,6 +182,17 @@ int rgfm_sample_pair(rgfm_unet* hx, rgfm_unet* hy, float* x_inout, float* y_inou
                      const float* mc_x1, const float* mc_y1, const float* mc_ratios, int n_mc,
                      int batch, int num_steps, double gamma, int step_begin, int step_end, void* ws,
                      size_t ws_bytes, rgfm_stream_t stream);
+
+/* Paired Euler loop with GRADIENT LOG-RATIO guidance, in place: every step
+ *     x <- x + (v_x(x, t) + gamma * d log r(x, y)/dx) dt,   y likewise
+ * (reference README.md:159-164, "v_guided = v_ind + gamma * grad log r(x_t, y_t)").  The reference ships no code
+ * for this mode, so the composition above is this library's reading of that line; the gradient itself is the
+ * autograd gradient of the reference module (rgfm_ratio_grad_log_ratio).  MNIST32 + SVHN pair only. */
+int rgfm_sample_pair_grad_workspace_bytes(const rgfm_unet* hx, const rgfm_unet* hy, const rgfm_ratio* hr,
+                                          int batch, size_t* bytes);
+int rgfm_sample_pair_grad(rgfm_unet* hx, rgfm_unet* hy, rgfm_ratio* hr, float* x_inout, float* y_inout,
+                          int batch, int num_steps, double gamma, int step_begin, int step_end, void* ws,
+                          size_t ws_bytes, rgfm_stream_t stream);
 
 /* ------------------------------------------------------------------ FlowMatchingModel ("--model original")
  * The reference's encoder-decoder velocity net (src/models/flow_matching.py:127-173;

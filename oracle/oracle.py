@@ -46,7 +46,8 @@ def lib():
         L.ro_unet_num_activations.restype = ctypes.c_int
         L.ro_num_threads.restype = ctypes.c_int
         for f in (L.ro_unet_forward, L.ro_ratio_eval, L.ro_guidance_apply, L.ro_sample_single,
-                  L.ro_sample_pair, L.ro_timestep_embedding, L.ro_unet_activation_shape):
+                  L.ro_sample_pair, L.ro_timestep_embedding, L.ro_unet_activation_shape, L.ro_ratio_grad,
+                  L.ro_sample_pair_grad):
             f.restype = None
         _lib = L
     return _lib
@@ -139,6 +140,33 @@ def ratio_eval(kind, params, x, y, what="log_ratio", loss="disc", feature_dim=25
                     out.ctypes.data_as(F32P), n, _WHAT[what],
                     feat.ctypes.data_as(F32P) if want_feat else None)
     return (out, feat) if want_feat else out
+
+
+def ratio_grad(params, x, y, loss="disc", feature_dim=256, hidden_dim=512):
+    """(d log_ratio / dx, d log_ratio / dy, log_ratio) of RatioEstimatorMNISTSVHN in eval mode."""
+    L = lib()
+    params, pp = _f(params)
+    x, xp = _f(x)
+    y, yp = _f(y)
+    n = x.shape[0]
+    gx, gy, lr = np.empty_like(x), np.empty_like(y), np.empty(n, np.float32)
+    L.ro_ratio_grad(feature_dim, hidden_dim, _LOSS[loss], pp, xp, yp, gx.ctypes.data_as(F32P),
+                    gy.ctypes.data_as(F32P), lr.ctypes.data_as(F32P), n)
+    return gx, gy, lr
+
+
+def sample_pair_grad(desc_x, params_x, desc_y, params_y, ratio_params, x0, y0, num_steps, gamma, loss="disc",
+                     step_begin=0, step_end=None, feature_dim=256, hidden_dim=512):
+    px, pxp = _f(params_x)
+    py, pyp = _f(params_y)
+    pr, prp = _f(ratio_params)
+    x = np.array(x0, dtype=np.float32, order="C")
+    y = np.array(y0, dtype=np.float32, order="C")
+    lib().ro_sample_pair_grad(ctypes.byref(desc_x), pxp, ctypes.byref(desc_y), pyp, feature_dim, hidden_dim,
+                              _LOSS[loss], prp, x.ctypes.data_as(F32P), y.ctypes.data_as(F32P), x.shape[0],
+                              num_steps, ctypes.c_double(gamma), step_begin,
+                              num_steps if step_end is None else step_end)
+    return x, y
 
 
 def guidance_apply(x, y, vx, vy, mc_x1, mc_y1, mc_ratios, t, gamma, want_weights=False):

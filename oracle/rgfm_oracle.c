@@ -641,6 +641,274 @@ void ro_ratio_eval(int kind, int feature_dim, int hidden_dim, int loss, const fl
                feat ? feat + (size_t)i * 2 * feature_dim : NULL);
 }
 
+/* ---------------------------------------------------------------- gradient of log r
+ * d log_ratio(x, y) / d(x, y) of RatioEstimatorMNISTSVHN (src/models/ratio_flexible.py:347-385): what
+ * torch.autograd.grad(model.log_ratio(x, y).sum(), (x, y)) returns for the reference module in eval mode
+ * (BatchNorm on running statistics, Dropout off).  Hand-written reverse pass, one sample at a time:
+ * forward with every pre-activation kept, then head -> score_net (Linear / LayerNorm / SiLU) -> the two
+ * encoders (Linear, AdaptiveAvgPool, [SiLU, BatchNorm(eval), Conv3x3, MaxPool2] blocks). */
+
+static inline float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+static inline float dsilu(float v) {
+  const float s = sigmoidf_(v);
+  return s * (1.0f + v * (1.0f - s));
+}
+
+/* gradient of conv3x3 (pad 1, stride 1) wrt its input: gin[ci,y,x] = sum_co,ky,kx w[co,ci,ky,kx] g[co,y-ky+1,x-kx+1] */
+static void conv3x3_bwd_data(const float* g, int Co, int S, const float* w, int Ci, float* gin) {
+  memset(gin, 0, (size_t)Ci * S * S * sizeof(float));
+  for (int co = 0; co < Co; ++co)
+    for (int ci = 0; ci < Ci; ++ci) {
+      const float* wk = w + ((size_t)co * Ci + ci) * 9;
+      const float* gp = g + (size_t)co * S * S;
+      float* o = gin + (size_t)ci * S * S;
+      for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) {
+          const float wv = wk[ky * 3 + kx];
+          /* output pixel (yo, xo) read input (yo + ky - 1, xo + kx - 1) */
+          for (int yo = 0; yo < S; ++yo) {
+            const int yi = yo + ky - 1;
+            if (yi < 0 || yi >= S) continue;
+            for (int xo = 0; xo < S; ++xo) {
+              const int xi = xo + kx - 1;
+              if (xi < 0 || xi >= S) continue;
+              o[(size_t)yi * S + xi] += wv * gp[(size_t)yo * S + xo];
+            }
+          }
+        }
+    }
+}
+
+typedef struct {
+  int ci, co, S, pooled;
+  const float *cw, *bw, *bb, *rm, *rv;
+  float* z; /* BatchNorm output (pre-SiLU) [co,S,S] */
+} enc_layer;
+
+/* forward of one BatchNorm encoder with the pre-activations kept; returns the number of layers */
+static void bn_encoder_fwd_keep(cursor* c, const float* img, int S, const int* chans, int nconv, const int* pool_after,
+                                int F, enc_layer* L, const float** fw_out, float* feat) {
+  float* h = fmalloc((size_t)chans[0] * S * S);
+  memcpy(h, img, (size_t)chans[0] * S * S * sizeof(float));
+  for (int i = 0; i < nconv; ++i) {
+    const int ci = chans[i], co = chans[i + 1];
+    L[i].ci = ci, L[i].co = co, L[i].S = S, L[i].pooled = pool_after[i];
+    L[i].cw = take(c, (size_t)co * ci * 9);
+    const float* cb = take(c, co);
+    L[i].bw = take(c, co), L[i].bb = take(c, co), L[i].rm = take(c, co), L[i].rv = take(c, co);
+    take(c, 1);
+    float* z = fmalloc((size_t)co * S * S);
+    conv3x3(h, ci, S, S, L[i].cw, cb, co, 1, z);
+    free(h);
+    for (int ch = 0; ch < co; ++ch) {
+      const float inv = 1.0f / sqrtf(L[i].rv[ch] + 1e-5f);
+      for (int p = 0; p < S * S; ++p) z[(size_t)ch * S * S + p] = (z[(size_t)ch * S * S + p] - L[i].rm[ch]) * inv * L[i].bw[ch] + L[i].bb[ch];
+    }
+    L[i].z = z;
+    h = fmalloc((size_t)co * S * S);
+    for (size_t p = 0; p < (size_t)co * S * S; ++p) h[p] = silu(z[p]);
+    if (pool_after[i]) h = maxpool2(h, co, &S);
+  }
+  const float* fw = take(c, (size_t)F * chans[nconv]);
+  const float* fb = take(c, F);
+  *fw_out = fw;
+  avgpool_fc(h, chans[nconv], S * S, fw, fb, F, feat);
+  free(h);
+}
+
+/* reverse pass of one encoder: gfeat [F] -> gimg [chans[0], 32, 32]; frees the kept pre-activations */
+static void bn_encoder_bwd(enc_layer* L, int nconv, const float* fw, int F, const float* gfeat, float* gimg) {
+  const int Cl = L[nconv - 1].co;
+  int S = L[nconv - 1].pooled ? L[nconv - 1].S / 2 : L[nconv - 1].S; /* map size in front of the average pool */
+  /* fc + AdaptiveAvgPool2d(1) */
+  float* g = fmalloc((size_t)Cl * S * S);
+  for (int ch = 0; ch < Cl; ++ch) {
+    float a = 0.0f;
+    for (int f = 0; f < F; ++f) a += fw[(size_t)f * Cl + ch] * gfeat[f];
+    a /= (float)(S * S);
+    for (int p = 0; p < S * S; ++p) g[(size_t)ch * S * S + p] = a;
+  }
+  for (int i = nconv - 1; i >= 0; --i) {
+    const int co = L[i].co, ci = L[i].ci, Sz = L[i].S;
+    float* gz = fmalloc((size_t)co * Sz * Sz);
+    if (L[i].pooled) {
+      /* F.max_pool2d(h, 2) backward: the gradient goes to the first maximum of the window (scan order ky, kx,
+       * strict '>' as ATen's CPU kernel), then SiLU' */
+      const int So = Sz / 2;
+      memset(gz, 0, (size_t)co * Sz * Sz * sizeof(float));
+      for (int ch = 0; ch < co; ++ch)
+        for (int y = 0; y < So; ++y)
+          for (int x = 0; x < So; ++x) {
+            const float* zp = L[i].z + ((size_t)ch * Sz + 2 * y) * Sz + 2 * x;
+            int best = 0;
+            float bv = silu(zp[0]);
+            const int offs[4] = {0, 1, Sz, Sz + 1};
+            for (int k = 1; k < 4; ++k) {
+              const float v = silu(zp[offs[k]]);
+              if (v > bv) bv = v, best = k;
+            }
+            const size_t o = ((size_t)ch * Sz + 2 * y) * Sz + 2 * x + offs[best];
+            gz[o] = g[((size_t)ch * So + y) * So + x] * dsilu(L[i].z[o]);
+          }
+    } else {
+      for (size_t p = 0; p < (size_t)co * Sz * Sz; ++p) gz[p] = g[p] * dsilu(L[i].z[p]);
+    }
+    free(g);
+    /* BatchNorm (eval): z = (u - rm) * inv * w + b -> du = dz * inv * w */
+    for (int ch = 0; ch < co; ++ch) {
+      const float sc = L[i].bw[ch] / sqrtf(L[i].rv[ch] + 1e-5f);
+      for (int p = 0; p < Sz * Sz; ++p) gz[(size_t)ch * Sz * Sz + p] *= sc;
+    }
+    float* gin = i == 0 ? gimg : fmalloc((size_t)ci * Sz * Sz);
+    conv3x3_bwd_data(gz, co, Sz, L[i].cw, ci, gin);
+    free(gz);
+    free(L[i].z);
+    g = gin;
+  }
+}
+
+/* loss: 0 disc, 1 rulsif.  gx [1,32,32], gy [3,32,32]; returns log_ratio */
+static float ratio_grad_one(int F, int Hd, const float* params, const float* x, const float* y, int loss, float* gx,
+                            float* gy) {
+  static const int cm[5] = {1, 32, 64, 128, 128}, pm[4] = {1, 1, 1, 0};
+  static const int cs[9] = {3, 64, 64, 128, 128, 256, 256, 256, 256};
+  static const int ps[8] = {0, 1, 0, 1, 0, 1, 0, 1};
+  cursor c = {params};
+  enc_layer Lm[4], Ls[8];
+  const float *fwm, *fws;
+  float feat[1024];
+  bn_encoder_fwd_keep(&c, x, 32, cm, 4, pm, F, Lm, &fwm, feat);
+  bn_encoder_fwd_keep(&c, y, 32, cs, 8, ps, F, Ls, &fws, feat + F);
+  /* score_net forward, inputs and pre-LayerNorm values kept */
+  const int dims[4] = {2 * F, Hd, Hd, Hd / 2};
+  const float *W[3], *lw[3];
+  float *in[4], *u[3];
+  float mean[3], rstd[3];
+  in[0] = fmalloc(2 * F);
+  memcpy(in[0], feat, 2 * F * sizeof(float));
+  for (int l = 0; l < 3; ++l) {
+    W[l] = take(&c, (size_t)dims[l + 1] * dims[l]);
+    const float* b = take(&c, dims[l + 1]);
+    lw[l] = take(&c, dims[l + 1]);
+    const float* lb = take(&c, dims[l + 1]);
+    const int n = dims[l + 1];
+    u[l] = fmalloc(n);
+    linear(W[l], b, in[l], dims[l], n, u[l]);
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += u[l][i];
+    const double mu = s / n;
+    double m2 = 0.0;
+    for (int i = 0; i < n; ++i) m2 += (u[l][i] - mu) * (u[l][i] - mu);
+    mean[l] = (float)mu, rstd[l] = (float)(1.0 / sqrt(m2 / n + 1e-5));
+    in[l + 1] = fmalloc(n);
+    for (int i = 0; i < n; ++i) in[l + 1][i] = silu((u[l][i] - mean[l]) * rstd[l] * lw[l][i] + lb[i]);
+    /* keep v = LN output in u[l] slot? no: recomputed below from u, mean, rstd */
+    (void)lb;
+  }
+  const float* hw = take(&c, dims[3]);
+  const float* hb = take(&c, 1);
+  float s;
+  linear(hw, hb, in[3], dims[3], 1, &s);
+  float lr, ds;
+  if (loss == 0) {
+    lr = logsigmoidf(s) - logsigmoidf(-s);
+    ds = sigmoidf_(-s) + sigmoidf_(s); /* d logsigmoid(s) - d logsigmoid(-s) */
+  } else {
+    const float w = s > 20.0f ? s : log1pf(expf(s));
+    lr = logf(w + 1e-8f);
+    ds = (s > 20.0f ? 1.0f : sigmoidf_(s)) / (w + 1e-8f);
+  }
+  /* reverse: head */
+  float* g = fmalloc(dims[3]);
+  for (int i = 0; i < dims[3]; ++i) g[i] = ds * hw[i];
+  /* the LayerNorm biases are needed again: re-walk the parameter block */
+  cursor c2 = {params};
+  ratio_walk(RO_RATIO_MNIST_SVHN, F, Hd, NULL, NULL, NULL, 0, 0, NULL, NULL); /* (layout check only) */
+  {
+    /* skip the encoders */
+    for (int i = 0; i < 4; ++i) take(&c2, (size_t)cm[i + 1] * cm[i] * 9 + 5 * cm[i + 1] + 1);
+    take(&c2, (size_t)F * 128 + F);
+    for (int i = 0; i < 8; ++i) take(&c2, (size_t)cs[i + 1] * cs[i] * 9 + 5 * cs[i + 1] + 1);
+    take(&c2, (size_t)F * 256 + F);
+  }
+  const float* lbs[3];
+  for (int l = 0; l < 3; ++l) {
+    take(&c2, (size_t)dims[l + 1] * dims[l]);
+    take(&c2, dims[l + 1]);
+    take(&c2, dims[l + 1]);
+    lbs[l] = take(&c2, dims[l + 1]);
+  }
+  for (int l = 2; l >= 0; --l) {
+    const int n = dims[l + 1];
+    /* y = silu(v), v = gamma * uhat + beta, uhat = (u - mean) * rstd */
+    float* guh = fmalloc(n);
+    double m1 = 0.0, m2 = 0.0;
+    for (int i = 0; i < n; ++i) {
+      const float uh = (u[l][i] - mean[l]) * rstd[l];
+      const float v = uh * lw[l][i] + lbs[l][i];
+      guh[i] = g[i] * dsilu(v) * lw[l][i];
+      m1 += guh[i];
+      m2 += (double)guh[i] * uh;
+    }
+    m1 /= n, m2 /= n;
+    float* gu = fmalloc(n);
+    for (int i = 0; i < n; ++i) {
+      const float uh = (u[l][i] - mean[l]) * rstd[l];
+      gu[i] = rstd[l] * (guh[i] - (float)m1 - uh * (float)m2);
+    }
+    free(guh);
+    free(g);
+    g = fmalloc(dims[l]);
+    for (int k = 0; k < dims[l]; ++k) {
+      float a = 0.0f;
+      for (int o = 0; o < n; ++o) a += W[l][(size_t)o * dims[l] + k] * gu[o];
+      g[k] = a;
+    }
+    free(gu);
+  }
+  bn_encoder_bwd(Lm, 4, fwm, F, g, gx);
+  bn_encoder_bwd(Ls, 8, fws, F, g + F, gy);
+  free(g);
+  for (int l = 0; l < 3; ++l) free(u[l]);
+  for (int l = 0; l < 4; ++l) free(in[l]);
+  return lr;
+}
+
+void ro_ratio_grad(int feature_dim, int hidden_dim, int loss, const float* params, const float* x, const float* y,
+                   float* gx, float* gy, float* log_ratio, int n) {
+#pragma omp parallel for schedule(dynamic)
+  for (int i = 0; i < n; ++i) {
+    const float lr = ratio_grad_one(feature_dim, hidden_dim, params, x + (size_t)i * 1024, y + (size_t)i * 3072, loss,
+                                    gx + (size_t)i * 1024, gy + (size_t)i * 3072);
+    if (log_ratio) log_ratio[i] = lr;
+  }
+}
+
+/* Gradient log-ratio guidance (reference README.md:159-164: v_guided = v_ind + gamma * grad log r(x_t, y_t)), explicit
+ * Euler as the other samplers: x <- x + (v_x + gamma g_x) dt.  The reference ships no code for this mode: the
+ * composition is this build's reading of the README line ("parity unpinned"); the gradient itself is pinned. */
+void ro_sample_pair_grad(const ro_unet_desc* ddx, const float* px, const ro_unet_desc* ddy, const float* py,
+                         int feature_dim, int hidden_dim, int loss, const float* pr, float* x, float* y, int B,
+                         int num_steps, double gamma, int step_begin, int step_end) {
+  const size_t dx = (size_t)ddx->in_channels * ddx->img_size * ddx->img_size;
+  const size_t dy = (size_t)ddy->in_channels * ddy->img_size * ddy->img_size;
+  float* vx = fmalloc(B * dx);
+  float* vy = fmalloc(B * dy);
+  float* gx = fmalloc(B * dx);
+  float* gy = fmalloc(B * dy);
+  const double dtd = 1.0 / (double)num_steps;
+  const float dt = (float)dtd, gf = (float)gamma;
+  for (int s = step_begin; s < step_end; ++s) {
+    const float t = (float)((double)s * dtd);
+    ro_unet_forward(ddx, px, x, &t, 1, vx, B, NULL);
+    ro_unet_forward(ddy, py, y, &t, 1, vy, B, NULL);
+    ro_ratio_grad(feature_dim, hidden_dim, loss, pr, x, y, gx, gy, NULL, B);
+    for (size_t i = 0; i < B * dx; ++i) x[i] = x[i] + (vx[i] + gf * gx[i]) * dt;
+    for (size_t i = 0; i < B * dy; ++i) y[i] = y[i] + (vy[i] + gf * gy[i]) * dt;
+  }
+  free(vx), free(vy), free(gx), free(gy);
+}
+
 /* ---------------------------------------------------------------- guidance + Euler */
 
 /* MC importance-weighted guidance block (src/sample_mnist_svhn.py:124-171,

@@ -363,6 +363,33 @@ class RatioEngine(_EngineBase):
         return out
 
 
+    def grad_log_ratio(self, x, y):
+        """(d log_ratio/dx, d log_ratio/dy, log_ratio): rgfm_ratio_grad_log_ratio (MNIST-SVHN estimator only)."""
+        m = self._module()
+        self._check_eval(m)
+        _require_hip(x, y)
+        if self.kind != "mnist_svhn":
+            raise _lib.RgfmError("the log-ratio gradient is implemented for RatioEstimatorMNISTSVHN only")
+        if x.shape[0] != y.shape[0]:
+            raise _lib.RgfmError("x and y must have the same batch size")
+        n = x.shape[0]
+        x, y = x.contiguous(), y.contiguous()
+        gx, gy = torch.empty_like(x), torch.empty_like(y)
+        lr = torch.empty(n, device=x.device, dtype=torch.float32)
+        if n == 0:
+            return gx, gy, lr
+        dev = x.device
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            h = self.handle(dev)
+            nb = ctypes.c_size_t()
+            _lib.check(L.rgfm_ratio_grad_workspace_bytes(h, n, ctypes.byref(nb)))
+            ws = self._ws.get(nb.value, dev)
+            _lib.check(L.rgfm_ratio_grad_log_ratio(h, _ptr(x), _ptr(y), _ptr(gx), _ptr(gy), _ptr(lr), n, _ptr(ws),
+                                                   nb.value, _stream(dev)))
+        return gx, gy, lr
+
+
 # ---- sampler entry points ------------------------------------------------
 
 _sampler_ws = _Workspace()
@@ -460,6 +487,36 @@ def sample_pair(fm_x, fm_y, x, y, mc_x1, mc_y1, mc_ratios, num_steps, gamma, ste
                                           _ptr(mc_ratios if n_mc else None), n_mc, B, int(num_steps),
                                           float(gamma), int(step_begin), int(step_end), _ptr(ws),
                                           nb.value, _stream(dev)))
+        return x, y
+    return _range_guarded(dev, [x, y], run)
+
+
+def sample_pair_grad(fm_x, fm_y, ratio_estimator, x, y, num_steps, gamma, step_begin=0, step_end=None):
+    """In-place paired Euler loop with gradient log-ratio guidance (rgfm_sample_pair_grad)."""
+    for m in (fm_x, fm_y, ratio_estimator):
+        m._engine._check_eval(m)
+    if not (isinstance(fm_x._engine, UNetEngine) and isinstance(fm_y._engine, UNetEngine)):
+        raise _lib.RgfmError("gradient log-ratio guidance needs two U-Net velocity nets")
+    if ratio_estimator._engine.kind != "mnist_svhn":
+        raise _lib.RgfmError("gradient log-ratio guidance is implemented for RatioEstimatorMNISTSVHN only")
+    _require_hip(x, y)
+    if not (x.is_contiguous() and y.is_contiguous()):
+        raise _lib.RgfmError("x and y must be contiguous (they are updated in place)")
+    if step_end is None:
+        step_end = num_steps
+    B, dev = x.shape[0], x.device
+    if B == 0:
+        return x, y
+    L = _lib.lib()
+
+    def run():
+        with torch.cuda.device(dev):
+            hx, hy, hr = fm_x._engine.handle(dev), fm_y._engine.handle(dev), ratio_estimator._engine.handle(dev)
+            nb = ctypes.c_size_t()
+            _lib.check(L.rgfm_sample_pair_grad_workspace_bytes(hx, hy, hr, B, ctypes.byref(nb)))
+            ws = _sampler_ws.get(nb.value, dev)
+            _lib.check(L.rgfm_sample_pair_grad(hx, hy, hr, _ptr(x), _ptr(y), B, int(num_steps), float(gamma),
+                                               int(step_begin), int(step_end), _ptr(ws), nb.value, _stream(dev)))
         return x, y
     return _range_guarded(dev, [x, y], run)
 

@@ -51,6 +51,12 @@ SIGNATURES = {
     "rgfm_ratio_workspace_bytes": (c_int, [c_void_p, c_int, P(c_size_t)]),
     "rgfm_ratio_eval": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                 c_size_t, c_void_p]),
+    "rgfm_ratio_grad_workspace_bytes": (c_int, [c_void_p, c_int, P(c_size_t)]),
+    "rgfm_ratio_grad_log_ratio": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                          c_void_p, c_size_t, c_void_p]),
+    "rgfm_sample_pair_grad_workspace_bytes": (c_int, [c_void_p, c_void_p, c_void_p, c_int, P(c_size_t)]),
+    "rgfm_sample_pair_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_double,
+                                      c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "rgfm_sample_single_workspace_bytes": (c_int, [c_void_p, c_int, P(c_size_t)]),
     "rgfm_sample_single": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                    c_size_t, c_void_p]),

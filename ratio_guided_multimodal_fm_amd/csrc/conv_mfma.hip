@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
       for (int nt = 0; nt < NT; ++nt) {
         const int c = n0 + nt * 32 + l31;
         float v = acc[mt][nt][r];
-        if (a.ep_scale) v = silu_f(v * eps_[nt] + eph_[nt]);
+        if (a.ep_scale) v = a.ep_nosilu ? v * eps_[nt] + eph_[nt] : silu_f(v * eps_[nt] + eph_[nt]);
         acc[mt][nt][r] = v;
         if (valid) a.out[pix * a.Cout + c] = v;
       }
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pf_kernel(const ConvArgs a) 
       for (int nt = 0; nt < NT; ++nt) {
         const int c = n0 + nt * 32 + l31;
         float v = acc[mt][nt][r];
-        if (a.ep_scale) v = silu_f(v * eps_[nt] + eph_[nt]);
+        if (a.ep_scale) v = a.ep_nosilu ? v * eps_[nt] + eph_[nt] : silu_f(v * eps_[nt] + eph_[nt]);
         acc[mt][nt][r] = v;
         if (valid) a.out[pix * a.Cout + c] = v;
       }

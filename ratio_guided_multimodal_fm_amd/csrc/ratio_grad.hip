@@ -1,0 +1,252 @@
+// ratio_grad.hip -- reverse pass of RatioEstimatorMNISTSVHN (src/models/ratio_flexible.py:185-385) for the
+// gradient log-ratio guidance v + gamma * grad log r(x_t, y_t) (reference README.md:159-164).
+// The 3x3 data gradients run on the fp32 MFMA conv (conv_mfma.hip) with the weights transposed and the taps
+// flipped, the dense ones on linear_mfma; this file holds what is left: SiLU' / BatchNorm-scale / max-pool and
+// average-pool routing, the image-side conv gradient, LayerNorm+SiLU backward, the head, and the Euler update.
+#include "rgfm_device.h"
+
+namespace rgfm {
+
+__device__ __forceinline__ float sigmoid_g(float v) { return 1.0f / (1.0f + expf(-v)); }
+__device__ __forceinline__ float dsilu_g(float v) {
+  const float s = sigmoid_g(v);
+  return s * (1.0f + v * (1.0f - s));
+}
+
+__global__ void conv_weight_transpose_kernel(const float* w, float* wt, int Co, int Ci) {
+  const size_t total = (size_t)Co * Ci * 9;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int k = i % 9;
+    const size_t r = i / 9;
+    const int co = r % Co, ci = r / Co;  // i indexes wt[ci][co][k]
+    wt[i] = w[((size_t)co * Ci + ci) * 9 + (8 - k)];
+  }
+}
+void launch_conv_weight_transpose(const float* w, float* wt, int Co, int Ci, hipStream_t s) {
+  hipLaunchKernelGGL(conv_weight_transpose_kernel, dim3(256), dim3(256), 0, s, w, wt, Co, Ci);
+}
+
+__global__ void transpose2d_kernel(const float* w, float* wt, int rows, int cols) {
+  const size_t total = (size_t)rows * cols;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = i % rows;
+    const size_t c = i / rows;  // i indexes wt[c][r]
+    wt[i] = w[(size_t)r * cols + c];
+  }
+}
+void launch_transpose2d(const float* w, float* wt, int rows, int cols, hipStream_t s) {
+  hipLaunchKernelGGL(transpose2d_kernel, dim3(256), dim3(256), 0, s, w, wt, rows, cols);
+}
+
+__global__ void fill_kernel(float* p, float v, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+void launch_fill(float* p, float v, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(fill_kernel, dim3(n < 65536 ? (unsigned)((n + 255) / 256) : 256u), dim3(256), 0, s, p, v, n);
+}
+__global__ void fill_ab_kernel(float* ab, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    ab[2 * i] = 1.f, ab[2 * i + 1] = 0.f;
+}
+void launch_fill_ab_identity(float* ab, size_t n_pairs, hipStream_t s) {
+  hipLaunchKernelGGL(fill_ab_kernel, dim3(256), dim3(256), 0, s, ab, n_pairs);
+}
+
+// one thread per (sample, output-side pixel group, 4 channels)
+__global__ void grad_act_kernel(const float* g, const float* z, const float* scale, float* gz, int B, int S, int C, int mode) {
+  const int C4 = C / 4;
+  if (mode == 1 || mode == 3) {
+    const int So = S / 2;
+    const float inv_o = 1.0f / (float)(So * So);
+    const size_t total = (size_t)B * So * So * C4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+      const int c4 = i % C4;
+      size_t r = i / C4;
+      const int ox = r % So;
+      r /= So;
+      const int oy = r % So;
+      const int b = r / So;
+      f32x4 gv;
+      if (mode == 3) gv = *reinterpret_cast<const f32x4*>(g + (size_t)b * C + c4 * 4) * inv_o;
+      else gv = *reinterpret_cast<const f32x4*>(g + ((size_t)(b * So + oy) * So + ox) * C + c4 * 4);
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
+      f32x4 zv[4];
+      size_t off[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        off[k] = ((size_t)(b * S + 2 * oy + (k >> 1)) * S + 2 * ox + (k & 1)) * C + c4 * 4;
+        zv[k] = *reinterpret_cast<const f32x4*>(z + off[k]);
+      }
+      f32x4 o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // F.max_pool2d backward: the first maximum of silu(z) in scan order (ky, kx), strict '>'
+        int best = 0;
+        float bv = silu_f(zv[0][e]);
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+          const float v = silu_f(zv[k][e]);
+          if (v > bv) bv = v, best = k;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k == best) o[k][e] = gv[e] * dsilu_g(zv[k][e]) * sc[e];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(gz + off[k]) = o[k];
+    }
+  } else {
+    const size_t total = (size_t)B * S * S * C4;
+    const float inv = 1.0f / (float)(S * S);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+      const int c4 = i % C4;
+      const size_t px = i / C4;
+      const size_t b = px / ((size_t)S * S);
+      const f32x4 zv = *reinterpret_cast<const f32x4*>(z + px * C + c4 * 4);
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
+      f32x4 gv;
+      if (mode == 2) {
+        gv = *reinterpret_cast<const f32x4*>(g + b * C + c4 * 4);
+        gv = gv * inv;
+      } else {
+        gv = *reinterpret_cast<const f32x4*>(g + px * C + c4 * 4);
+      }
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = gv[e] * dsilu_g(zv[e]) * sc[e];
+      *reinterpret_cast<f32x4*>(gz + px * C + c4 * 4) = o;
+    }
+  }
+}
+void launch_grad_act(const float* g, const float* z, const float* scale, float* gz, int B, int S, int C, int mode, hipStream_t s) {
+  const size_t total = (size_t)B * ((mode == 1 || mode == 3) ? (S / 2) * (S / 2) : S * S) * (C / 4);
+  const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(grad_act_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, g, z, scale, gz, B, S, C, mode);
+}
+
+// gimg[b][c][y][x] = sum_{co, ky, kx} w[co][c][ky][kx] gz[b][y - ky + 1][x - kx + 1][co]; one wave per output
+// pixel, lanes over co (Co = 32 or 64), the CIMG x 9 partial sums reduced across the wave
+template <int CIMG>
+__global__ __launch_bounds__(256) void conv_bwd_img_kernel(const float* gz, const float* w, float* gimg, int B, int S, int Co) {
+  const int lane = threadIdx.x & 63;
+  const size_t px = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (px >= (size_t)B * S * S) return;
+  const int x = px % S;
+  const int y = (px / S) % S;
+  const size_t b = px / ((size_t)S * S);
+  float acc[CIMG];
+#pragma unroll
+  for (int c = 0; c < CIMG; ++c) acc[c] = 0.f;
+  for (int co = lane; co < Co; co += 64) {
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yo = y - ky + 1;
+      if (yo < 0 || yo >= S) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int xo = x - kx + 1;
+        if (xo < 0 || xo >= S) continue;
+        const float gv = gz[((b * S + yo) * S + xo) * Co + co];
+#pragma unroll
+        for (int c = 0; c < CIMG; ++c) acc[c] += w[((size_t)co * CIMG + c) * 9 + ky * 3 + kx] * gv;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CIMG; ++c) {
+    float v = acc[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) gimg[((b * CIMG + c) * S + y) * S + x] = v;
+  }
+}
+void launch_conv_bwd_img(const float* gz, const float* w, float* gimg, int B, int S, int Co, int cimg, hipStream_t s) {
+  const unsigned blocks = (unsigned)(((size_t)B * S * S + 3) / 4);
+  if (cimg == 1) hipLaunchKernelGGL(conv_bwd_img_kernel<1>, dim3(blocks), dim3(256), 0, s, gz, w, gimg, B, S, Co);
+  else hipLaunchKernelGGL(conv_bwd_img_kernel<3>, dim3(blocks), dim3(256), 0, s, gz, w, gimg, B, S, Co);
+}
+
+__device__ __forceinline__ float wsum_g(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// y = silu(v), v = w * uhat + b, uhat = (u - mean) * rstd:  gu = rstd * (guh - mean(guh) - uhat * mean(guh * uhat)),
+// guh = gy * silu'(v) * w.  Wave per row (statistics recomputed exactly as the forward kernel does).
+__global__ __launch_bounds__(256) void layernorm_silu_bwd_kernel(const float* u, const float* gy, const float* w, const float* b,
+                                                                 float* gu, int rows, int n) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* p = u + (size_t)row * n;
+  const float* q = gy + (size_t)row * n;
+  float s = 0.f;
+  for (int i = lane; i < n; i += 64) s += p[i];
+  const float mean = wsum_g(s) / (float)n;
+  float m2 = 0.f;
+  for (int i = lane; i < n; i += 64) {
+    const float d = p[i] - mean;
+    m2 += d * d;
+  }
+  const float rstd = 1.0f / sqrtf(wsum_g(m2) / (float)n + 1e-5f);
+  float a1 = 0.f, a2 = 0.f;
+  for (int i = lane; i < n; i += 64) {
+    const float uh = (p[i] - mean) * rstd;
+    const float guh = q[i] * dsilu_g(uh * w[i] + b[i]) * w[i];
+    a1 += guh, a2 += guh * uh;
+  }
+  a1 = wsum_g(a1) / (float)n, a2 = wsum_g(a2) / (float)n;
+  for (int i = lane; i < n; i += 64) {
+    const float uh = (p[i] - mean) * rstd;
+    const float guh = q[i] * dsilu_g(uh * w[i] + b[i]) * w[i];
+    gu[(size_t)row * n + i] = rstd * (guh - a1 - uh * a2);
+  }
+}
+void launch_layernorm_silu_bwd(const float* u, const float* gy, const float* w, const float* b, float* gu, int rows, int n,
+                               hipStream_t s) {
+  hipLaunchKernelGGL(layernorm_silu_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, u, gy, w, b, gu, rows, n);
+}
+
+__device__ __forceinline__ float logsigmoid_g(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
+
+// disc: log_ratio = logsigmoid(s) - logsigmoid(-s), d/ds = sigmoid(-s) + sigmoid(s); rulsif: log(softplus(s) + 1e-8),
+// d/ds = sigmoid(s) / (softplus(s) + 1e-8) (softplus threshold 20, ratio_flexible.py:379-383)
+__global__ void ratio_head_bwd_kernel(const float* score, const float* w, float* gh, float* log_ratio, int rows, int n, int loss) {
+  const size_t total = (size_t)rows * n;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int k = i % n;
+    const size_t row = i / n;
+    const float s = score[row];
+    float ds, lr;
+    if (loss == 0) {
+      ds = sigmoid_g(-s) + sigmoid_g(s);
+      lr = logsigmoid_g(s) - logsigmoid_g(-s);
+    } else {
+      const float sp = s > 20.f ? s : log1pf(expf(s));
+      ds = (s > 20.f ? 1.f : sigmoid_g(s)) / (sp + 1e-8f);
+      lr = logf(sp + 1e-8f);
+    }
+    gh[i] = ds * w[k];
+    if (log_ratio && k == 0) log_ratio[row] = lr;
+  }
+}
+void launch_ratio_head_bwd(const float* score, const float* w, float* gh, float* log_ratio, int rows, int n, int loss,
+                           hipStream_t s) {
+  const size_t total = (size_t)rows * n;
+  hipLaunchKernelGGL(ratio_head_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, score, w, gh, log_ratio,
+                     rows, n, loss);
+}
+
+__global__ void euler_grad_kernel(float* x, const float* v, const float* g, size_t n, float gamma, float dt) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    x[i] = __fadd_rn(x[i], __fmul_rn(fmaf(gamma, g[i], v[i]), dt));
+}
+void launch_euler_grad(float* x, const float* v, const float* g, size_t n, float gamma, float dt, hipStream_t s) {
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(euler_grad_kernel, dim3(blocks), dim3(256), 0, s, x, v, g, n, gamma, dt);
+}
+
+}  // namespace rgfm

@@ -1118,8 +1118,12 @@ struct rgfm_ratio {
   float* params = nullptr;
   float* packed = nullptr;
   float* bn = nullptr;  // folded BatchNorm scale/shift pairs
+  // gradient path (kind RGFM_RATIO_MNIST_SVHN): transposed weights, built at create time
+  float* gradw = nullptr;  // [packed W^T of every conv after the first | fc W^T | dense W^T | zeros]
+  size_t n_gradw = 0, g_zeros = 0;
   size_t n_params = 0, n_packed = 0, n_bn = 0;
   struct Conv {
+    size_t wt_pk = 0;  // packed transposed weights (offset into gradw), convs after the first
     ConvW w;
     size_t nw = 0, nb = 0;                 // GroupNorm weight/bias (mnist28) or BatchNorm w/b
     size_t rm = 0, rv = 0;                 // BatchNorm running stats
@@ -1130,11 +1134,13 @@ struct rgfm_ratio {
     int in_ch = 1, size = 32;
     std::vector<Conv> convs;
     size_t fcw = 0, fcb = 0;
+    size_t fcw_t = 0;  // fc weight transposed [fc_in][F] (offset into gradw)
     int fc_in = 0;
   };
   Encoder ex, ey;
   struct Dense {
     size_t w, b, lw, lb;
+    size_t w_t = 0;  // weight transposed [in][out] (offset into gradw)
     int in, out;
   };
   std::vector<Dense> hidden;
@@ -1147,7 +1153,7 @@ namespace {
 // Parameter order of RatioEstimatorMNISTSVHN (src/models/ratio_flexible.py:191-208,
 // :241-269, :327-345) and RatioEstimator (src/models/ratio_estimator.py:43-65, :121-135).
 size_t plan_ratio(const rgfm_ratio_desc& d, rgfm_ratio* h) {
-  Cursor c, pk, bn;
+  Cursor c, pk, bn, gw;
   const int F = d.feature_dim, Hd = d.hidden_dim;
   auto encoder = [&](int in_ch, int size, const std::vector<int>& chans, const std::vector<int>& pools, bool batchnorm) {
     rgfm_ratio::Encoder e;
@@ -1159,6 +1165,7 @@ size_t plan_ratio(const rgfm_ratio_desc& d, rgfm_ratio* h) {
       cv.w.w_raw = c.take((size_t)chans[i] * ci * 9);
       cv.w.b = c.take(chans[i]);
       if (i > 0) cv.w.w_pk = pk.take((size_t)chans[i] * ci * 9);
+      if (i > 0) cv.wt_pk = gw.take((size_t)chans[i] * ci * 9);
       cv.nw = c.take(chans[i]);
       cv.nb = c.take(chans[i]);
       if (batchnorm) {
@@ -1175,6 +1182,7 @@ size_t plan_ratio(const rgfm_ratio_desc& d, rgfm_ratio* h) {
     e.fc_in = ci;
     e.fcw = c.take((size_t)F * ci);
     e.fcb = c.take(F);
+    e.fcw_t = gw.take((size_t)F * ci);
     return e;
   };
   rgfm_ratio::Encoder ex, ey;
@@ -1193,6 +1201,7 @@ size_t plan_ratio(const rgfm_ratio_desc& d, rgfm_ratio* h) {
     rgfm_ratio::Dense dn;
     dn.in = dims[l], dn.out = dims[l + 1];
     dn.w = c.take((size_t)dn.in * dn.out), dn.b = c.take(dn.out);
+    dn.w_t = gw.take((size_t)dn.in * dn.out);
     dn.lw = c.take(dn.out), dn.lb = c.take(dn.out);
     hidden.push_back(dn);
   }
@@ -1200,6 +1209,8 @@ size_t plan_ratio(const rgfm_ratio_desc& d, rgfm_ratio* h) {
   if (h) {
     h->ex = ex, h->ey = ey, h->hidden = hidden, h->headw = headw, h->headb = headb, h->head_in = dims.back();
     h->n_packed = pk.off, h->n_bn = bn.off;
+    h->g_zeros = gw.take(1024);
+    h->n_gradw = gw.off;
   }
   return c.off;
 }
@@ -1351,6 +1362,28 @@ extern "C" int rgfm_ratio_create(const rgfm_ratio_desc* desc, const float* param
         launch_bn_fold(h->params + cv.nw, h->params + cv.nb, h->params + cv.rm, h->params + cv.rv,
                        h->bn + cv.bn_scale, h->bn + cv.bn_shift, cv.w.cout, s);
     }
+  if (desc->kind == RGFM_RATIO_MNIST_SVHN) {
+    // gradient path (rgfm_ratio_grad_log_ratio): dL/d(in) of a 3x3 conv is the conv of dL/d(out) with the weights
+    // transposed and the taps flipped; of a Linear, the Linear with W^T
+    if (hipMalloc(&h->gradw, (h->n_gradw + 4) * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(gradw)");
+    float* tmp = nullptr;
+    if (hipMalloc(&tmp, (size_t)256 * 256 * 9 * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(tmp)");
+    for (const auto* e : {&h->ex, &h->ey}) {
+      for (size_t i = 1; i < e->convs.size(); ++i) {
+        const auto& cv = e->convs[i];
+        launch_conv_weight_transpose(h->params + cv.w.w_raw, tmp, cv.w.cout, cv.w.cin, s);
+        launch_pack_conv(tmp, h->gradw + cv.wt_pk, cv.w.cin, cv.w.cout, 9, nt32_of(cv.w.cin), s);
+      }
+      launch_transpose2d(h->params + e->fcw, h->gradw + e->fcw_t, desc->feature_dim, e->fc_in, s);
+    }
+    for (const auto& dn : h->hidden) launch_transpose2d(h->params + dn.w, h->gradw + dn.w_t, dn.out, dn.in, s);
+    launch_fill(h->gradw + h->g_zeros, 0.f, 1024, s);
+    if (hipStreamSynchronize(s) != hipSuccess) {
+      (void)hipFree(tmp);
+      return bail(RGFM_EHIP, "building the transposed weights failed");
+    }
+    (void)hipFree(tmp);
+  }
   *out = h;
   return RGFM_OK;
 }
@@ -1360,6 +1393,7 @@ extern "C" void rgfm_ratio_destroy(rgfm_ratio* h) {
   if (h->params) (void)hipFree(h->params);
   if (h->packed) (void)hipFree(h->packed);
   if (h->bn) (void)hipFree(h->bn);
+  if (h->gradw) (void)hipFree(h->gradw);
   delete h;
 }
 
@@ -1385,6 +1419,268 @@ extern "C" int rgfm_ratio_eval(rgfm_ratio* h, const float* x, const float* y, fl
   b.base = (char*)ws, b.cap = ws_bytes, b.dry = false;
   RatioRun r{h, n, &b, (hipStream_t)stream, false};
   r.run(x, y, out, what);
+  HIP_TRY(hipGetLastError());
+  return RGFM_OK;
+}
+
+// ------------------------------------------------------------------ gradient of log r
+namespace {
+
+// Forward of RatioEstimatorMNISTSVHN with every pre-activation kept (BatchNorm output z of each conv, Linear output
+// u of each score_net layer), then the reverse pass down to the two images.  Same kernels as RatioRun for the
+// forward (the conv epilogue stores z instead of silu(z); SiLU is applied by the consumer through an identity
+// scale/shift array), conv_mfma with transposed weights / linear_mfma with W^T / ratio_grad.hip for the reverse.
+struct RatioGradRun {
+  rgfm_ratio* h;
+  int n;
+  Bump* ws;
+  hipStream_t s;
+  bool dry;
+  float* ab1 = nullptr;  // [n][256][2] identity scale/shift: "SiLU on load"
+
+  struct Kept {
+    float* z;
+    int C, S;
+    bool pooled;
+  };
+
+  float* encode(const rgfm_ratio::Encoder& e, const float* img, float* feat, int col0, std::vector<Kept>& kept) {
+    const int F = h->d.feature_dim;
+    int S = e.size;
+    const float* cur = nullptr;  // input of the next conv
+    bool cur_is_z = false;       // ... is a kept pre-activation (SiLU on load) rather than a pooled map
+    int curC = e.in_ch;
+    for (size_t i = 0; i < e.convs.size(); ++i) {
+      const rgfm_ratio::Conv& cv = e.convs[i];
+      const TileGeom g = make_geom(S, S);
+      float* z = ws->f((size_t)n * S * S * cv.w.cout);
+      if (!dry) {
+        if (i == 0) {
+          ConvInArgs ci{};
+          ci.x = img, ci.w = h->params + cv.w.w_raw, ci.bias = h->params + cv.w.b;
+          ci.ep_scale = h->bn + cv.bn_scale, ci.ep_shift = h->bn + cv.bn_shift, ci.ep_nosilu = 1;
+          ci.out = z, ci.stats_out = nullptr, ci.B = n, ci.C0 = cv.w.cout, ci.g = g;
+          launch_conv_in(ci, e.in_ch, s);
+        } else {
+          ConvArgs c{};
+          c.in0 = cur, c.C0 = curC, c.Hin = c.Win = S;
+          c.ab = cur_is_z ? ab1 : nullptr;
+          c.wpk = h->packed + cv.w.w_pk, c.bias = h->params + cv.w.b;
+          c.ep_scale = h->bn + cv.bn_scale, c.ep_shift = h->bn + cv.bn_shift, c.ep_nosilu = 1;
+          c.out = z, c.stats_out = nullptr, c.B = n, c.Cout = cv.w.cout, c.g = g;
+          c.halo_px = g.spt * (g.th + 2) * (g.W + 2);
+          launch_conv_mfma(c, CONV_S1, s);
+        }
+      }
+      kept.push_back({z, cv.w.cout, S, cv.pool_after});
+      curC = cv.w.cout;
+      if (cv.pool_after) {
+        float* pl = ws->f((size_t)n * (S / 2) * (S / 2) * curC);
+        if (!dry) launch_pool2(z, ab1, pl, n, S, S, curC, s);
+        cur = pl, cur_is_z = false;
+        S /= 2;
+      } else {
+        cur = z, cur_is_z = true;
+      }
+    }
+    float* pooled = ws->f((size_t)n * curC);
+    if (!dry) {
+      launch_avgpool(cur, cur_is_z ? ab1 : nullptr, pooled, n, S * S, curC, s);
+      launch_linear_mfma(pooled, h->params + e.fcw, h->params + e.fcb, feat + col0, n, curC, F, curC, 2 * F, s);
+    }
+    return pooled;
+  }
+
+  // reverse pass of one encoder: gfeat [n][2F] (columns col0 .. col0+F) -> gimg NCHW
+  void encode_bwd(const rgfm_ratio::Encoder& e, const std::vector<Kept>& kept, const float* gfeat, int col0, float* gimg) {
+    const int F = h->d.feature_dim;
+    const float* zeros = h->gradw + h->g_zeros;
+    const Kept& last = kept.back();
+    float* g = ws->f((size_t)n * last.C);  // gradient of the average-pooled vector
+    if (!dry) launch_linear_mfma(gfeat + col0, h->gradw + e.fcw_t, zeros, g, n, F, last.C, 2 * F, last.C, s);
+    int mode = 2;  // first step: g is [n][C] behind the global average pool
+    for (int i = (int)kept.size() - 1; i >= 0; --i) {
+      const Kept& k = kept[i];
+      const rgfm_ratio::Conv& cv = e.convs[i];
+      if (i != (int)kept.size() - 1) mode = k.pooled ? 1 : 0;
+      else mode = k.pooled ? 3 : 2;  // (SVHN encoder: a max-pool sits between the last conv and the average pool)
+      float* gz = ws->f((size_t)n * k.S * k.S * k.C);
+      if (!dry) launch_grad_act(g, k.z, h->bn + cv.bn_scale, gz, n, k.S, k.C, mode, s);
+      if (i == 0) {
+        if (!dry) launch_conv_bwd_img(gz, h->params + cv.w.w_raw, gimg, n, k.S, k.C, e.in_ch, s);
+      } else {
+        float* gin = ws->f((size_t)n * k.S * k.S * cv.w.cin);
+        if (!dry) {
+          ConvArgs c{};
+          c.in0 = gz, c.C0 = k.C, c.Hin = c.Win = k.S;
+          c.wpk = h->gradw + cv.wt_pk, c.bias = zeros;
+          c.out = gin, c.stats_out = nullptr, c.B = n, c.Cout = cv.w.cin;
+          c.g = make_geom(k.S, k.S);
+          c.halo_px = c.g.spt * (c.g.th + 2) * (c.g.W + 2);
+          launch_conv_mfma(c, CONV_S1, s);
+        }
+        g = gin;
+      }
+    }
+  }
+
+  void run(const float* x, const float* y, float* gx, float* gy, float* log_ratio) {
+    const int F = h->d.feature_dim;
+    ab1 = ws->f((size_t)n * 256 * 2);
+    if (!dry) launch_fill_ab_identity(ab1, (size_t)n * 256, s);
+    float* feat = ws->f((size_t)n * 2 * F);
+    std::vector<Kept> kx, ky;
+    encode(h->ex, x, feat, 0, kx);
+    encode(h->ey, y, feat, F, ky);
+    std::vector<float*> us, ins{feat};
+    float* cur = feat;
+    for (const auto& dn : h->hidden) {
+      float* u = ws->f((size_t)n * dn.out);
+      float* a = ws->f((size_t)n * dn.out);
+      if (!dry) {
+        launch_linear_mfma(cur, h->params + dn.w, h->params + dn.b, u, n, dn.in, dn.out, dn.in, dn.out, s);
+        (void)hipMemcpyAsync(a, u, (size_t)n * dn.out * sizeof(float), hipMemcpyDeviceToDevice, s);
+        launch_layernorm_silu(a, h->params + dn.lw, h->params + dn.lb, n, dn.out, s);
+      }
+      us.push_back(u);
+      cur = a;
+    }
+    float* score = ws->f(n);
+    float* g = ws->f((size_t)n * h->head_in);
+    if (!dry) {
+      launch_ratio_head(cur, h->params + h->headw, h->params + h->headb, score, n, h->head_in, h->d.loss_type, 0, s);
+      launch_ratio_head_bwd(score, h->params + h->headw, g, log_ratio, n, h->head_in, h->d.loss_type, s);
+    }
+    const float* zeros = h->gradw + h->g_zeros;
+    for (int l = (int)h->hidden.size() - 1; l >= 0; --l) {
+      const auto& dn = h->hidden[l];
+      float* gu = ws->f((size_t)n * dn.out);
+      float* gi = ws->f((size_t)n * dn.in);
+      if (!dry) {
+        launch_layernorm_silu_bwd(us[l], g, h->params + dn.lw, h->params + dn.lb, gu, n, dn.out, s);
+        launch_linear_mfma(gu, h->gradw + dn.w_t, zeros, gi, n, dn.out, dn.in, dn.out, dn.in, s);
+      }
+      g = gi;
+    }
+    encode_bwd(h->ex, kx, g, 0, gx);
+    encode_bwd(h->ey, ky, g, F, gy);
+  }
+};
+
+size_t ratio_grad_bytes(rgfm_ratio* h, int n) {
+  Bump b;
+  RatioGradRun r{h, n, &b, nullptr, true};
+  r.run(nullptr, nullptr, nullptr, nullptr, nullptr);
+  return b.off;
+}
+
+}  // namespace
+
+extern "C" int rgfm_ratio_grad_workspace_bytes(const rgfm_ratio* h, int n, size_t* bytes) {
+  if (!h || !bytes || n < 1) return fail(RGFM_EINVAL, "bad argument");
+  if (h->d.kind != RGFM_RATIO_MNIST_SVHN) return fail(RGFM_EINVAL, "the log-ratio gradient is implemented for RGFM_RATIO_MNIST_SVHN only");
+  *bytes = ratio_grad_bytes(const_cast<rgfm_ratio*>(h), n);
+  return RGFM_OK;
+}
+
+extern "C" int rgfm_ratio_grad_log_ratio(rgfm_ratio* h, const float* x, const float* y, float* gx, float* gy,
+                                         float* log_ratio_out, int n, void* ws, size_t ws_bytes, rgfm_stream_t stream) {
+  if (!h || !x || !y || !gx || !gy || !ws) return fail(RGFM_EINVAL, "null argument");
+  size_t need = 0;
+  int rc = rgfm_ratio_grad_workspace_bytes(h, n, &need);
+  if (rc) return rc;
+  if (need > ws_bytes) return fail(RGFM_ENOMEM, "workspace too small: %zu < %zu", ws_bytes, need);
+  refresh_modes();
+  Bump b;
+  b.base = (char*)ws, b.cap = ws_bytes, b.dry = false;
+  RatioGradRun r{h, n, &b, (hipStream_t)stream, false};
+  r.run(x, y, gx, gy, log_ratio_out);
+  HIP_TRY(hipGetLastError());
+  return RGFM_OK;
+}
+
+// Paired Euler loop with gradient log-ratio guidance (reference README.md:159-164: v_guided = v_ind + gamma *
+// grad log r(x_t, y_t); the reference ships no code for it): x <- x + (v_x + gamma dlogr/dx) dt, every step.
+extern "C" int rgfm_sample_pair_grad_workspace_bytes(const rgfm_unet* hx, const rgfm_unet* hy, const rgfm_ratio* hr, int batch,
+                                                     size_t* bytes) {
+  if (!hx || !hy || !hr || !bytes || batch < 1) return fail(RGFM_EINVAL, "bad argument");
+  size_t base = 0, rg = 0;
+  int rc = rgfm_sample_pair_workspace_bytes(hx, hy, batch, 0, &base);
+  if (rc) return rc;
+  if ((rc = rgfm_ratio_grad_workspace_bytes(hr, batch, &rg))) return rc;
+  const size_t dx = (size_t)hx->d.in_channels * hx->d.img_size * hx->d.img_size;
+  const size_t dy = (size_t)hy->d.in_channels * hy->d.img_size * hy->d.img_size;
+  *bytes = base + rg + ((batch * dx * 4 + 255) & ~(size_t)255) + ((batch * dy * 4 + 255) & ~(size_t)255);
+  return RGFM_OK;
+}
+
+extern "C" int rgfm_sample_pair_grad(rgfm_unet* hx, rgfm_unet* hy, rgfm_ratio* hr, float* x_inout, float* y_inout, int batch,
+                                     int num_steps, double gamma, int step_begin, int step_end, void* ws, size_t ws_bytes,
+                                     rgfm_stream_t stream) {
+  refresh_modes();
+  if (!hx || !hy || !hr || !x_inout || !y_inout || !ws) return fail(RGFM_EINVAL, "null argument");
+  if (hx->d.in_channels != 1 || hx->d.img_size != 32 || hy->d.in_channels != 3 || hy->d.img_size != 32)
+    return fail(RGFM_EINVAL, "gradient guidance needs the 1x32x32 + 3x32x32 pair of RatioEstimatorMNISTSVHN");
+  if (batch < 1 || num_steps < 1 || step_begin < 0 || step_end > num_steps || step_begin > step_end)
+    return fail(RGFM_EINVAL, "bad step range [%d,%d) of %d", step_begin, step_end, num_steps);
+  const int ns = step_end - step_begin;
+  if (ns > 4096) return fail(RGFM_EINVAL, "at most 4096 steps per call");
+  size_t need = 0;
+  int rc = rgfm_sample_pair_grad_workspace_bytes(hx, hy, hr, batch, &need);
+  if (rc) return rc;
+  if (need > ws_bytes) return fail(RGFM_ENOMEM, "workspace too small: %zu < %zu", ws_bytes, need);
+  if (ns == 0) return RGFM_OK;
+  DevState* ds = cur_dev();
+  if (!ds) return fail(RGFM_EINVAL, "no handle has been created on the current device");
+  hipStream_t s = (hipStream_t)stream;
+  const int dx = 1024, dy = 3072;
+  Bump b;
+  b.base = (char*)ws, b.cap = ws_bytes, b.dry = false;
+  float* tx = b.f((size_t)4096 * hx->temb_total);
+  float* ty = b.f((size_t)4096 * hy->temb_total);
+  float* vx = b.f((size_t)batch * dx);
+  float* vy = b.f((size_t)batch * dy);
+  float* gx = b.f((size_t)batch * dx);
+  float* gy = b.f((size_t)batch * dy);
+  unsigned* cnt_x = reinterpret_cast<unsigned*>(b.f(batch));
+  unsigned* cnt_y = reinterpret_cast<unsigned*>(b.f(batch));
+  HIP_TRY(hipMemsetAsync(cnt_x, 0, (size_t)batch * sizeof(unsigned), s));
+  HIP_TRY(hipMemsetAsync(cnt_y, 0, (size_t)batch * sizeof(unsigned), s));
+  launch_time_table(hx, nullptr, num_steps, step_begin, ns, tx, s);
+  launch_time_table(hy, nullptr, num_steps, step_begin, ns, ty, s);
+  const size_t mark_x = b.off;
+  const size_t mark_y = mark_x + unet_eval_bytes(hx, batch);
+  const size_t mark_r = mark_y + unet_eval_bytes(hy, batch);
+  const float dt = (float)(1.0 / (double)num_steps), gf = (float)gamma;
+  const bool overlap = g_modes.overlap;
+  for (int i = 0; i < ns; ++i) {
+    hipStream_t sy = overlap ? ds->side : s;
+    if (overlap) {
+      HIP_TRY(hipEventRecord(ds->fork, s));
+      HIP_TRY(hipStreamWaitEvent(ds->side, ds->fork, 0));
+    }
+    {
+      b.off = mark_y;
+      UNetRun r{hy, batch, &b, sy, ty + (size_t)i * hy->temb_total, 0, false};
+      r.fin_counter = cnt_y;
+      if ((rc = r.run(y_inout, vy, nullptr, 0.f))) return rc;
+    }
+    if (overlap) HIP_TRY(hipEventRecord(ds->join, ds->side));
+    {
+      b.off = mark_x;
+      UNetRun r{hx, batch, &b, s, tx + (size_t)i * hx->temb_total, 0, false};
+      r.fin_counter = cnt_x;
+      if ((rc = r.run(x_inout, vx, nullptr, 0.f))) return rc;
+    }
+    {
+      b.off = mark_r;
+      RatioGradRun r{hr, batch, &b, s, false};
+      r.run(x_inout, y_inout, gx, gy, nullptr);
+    }
+    if (overlap) HIP_TRY(hipStreamWaitEvent(s, ds->join, 0));
+    launch_euler_grad(x_inout, vx, gx, (size_t)batch * dx, gf, dt, s);
+    launch_euler_grad(y_inout, vy, gy, (size_t)batch * dy, gf, dt, s);
+  }
   HIP_TRY(hipGetLastError());
   return RGFM_OK;
 }

@@ -112,6 +112,7 @@ struct ConvArgs {
   // epilogue activation (ratio-net BatchNorm folded to scale/shift, then SiLU); null = none
   const float* ep_scale;
   const float* ep_shift;
+  int ep_nosilu;     // 1: store ep_scale * acc + ep_shift itself (the gradient path keeps the pre-activation)
   float* out;        // NHWC [B][H][W][Cout]
   float* stats_out;  // [B][nparts][Cout][2] or null
   // Producer-side GroupNorm finalize (conv_mfma_bx3.hip): when fin_ab is set, the LAST wave to deliver
@@ -135,6 +136,7 @@ struct ConvInArgs {  // first conv of a net: NCHW image -> NHWC features
   const float* bias;
   const float* ep_scale;  // optional BatchNorm scale/shift + SiLU epilogue (ratio nets)
   const float* ep_shift;
+  int ep_nosilu;          // 1: no SiLU (see ConvArgs::ep_nosilu)
   float* out;        // NHWC [B][H][W][C0]
   float* stats_out;  // or null
   int B, C0;
@@ -243,6 +245,25 @@ void launch_ratio_head(const float* x, const float* w, const float* b, float* ou
                        int loss, int what, hipStream_t s);
 void launch_bn_fold(const float* w, const float* b, const float* rm, const float* rv, float* scale,
                     float* shift, int C, hipStream_t s);
+
+// ---- gradient of log r (ratio_grad.hip)
+// [Co][Ci][9] -> [Ci][Co][9] with the taps flipped: the weights of the conv that maps dL/d(out) to dL/d(in)
+void launch_conv_weight_transpose(const float* w, float* wt, int Co, int Ci, hipStream_t s);
+void launch_transpose2d(const float* w, float* wt, int rows, int cols, hipStream_t s);  // [rows][cols] -> [cols][rows]
+void launch_fill(float* p, float v, size_t n, hipStream_t s);
+void launch_fill_ab_identity(float* ab, size_t n_pairs, hipStream_t s);  // (scale, shift) = (1, 0)
+// gz[b,y,x,c] = route * silu'(z) * scale[c].  mode 0: g has z's shape; 1: g is the 2x2-max-pooled map's gradient
+// (routed to the first maximum of silu(z) in each window); 2: g is [B][C], the gradient of the global average of
+// silu(z); 3: g is [B][C], the gradient of the global average of the 2x2-max-pooled map (modes 2 then 1 in one)
+void launch_grad_act(const float* g, const float* z, const float* scale, float* gz, int B, int S, int C, int mode, hipStream_t s);
+// first conv of an encoder, input gradient as an NCHW image: gimg[b,c,y,x] = sum_co,k w[co,c,k] gz[b, y-ky+1, x-kx+1, co]
+void launch_conv_bwd_img(const float* gz, const float* w, float* gimg, int B, int S, int Co, int cimg, hipStream_t s);
+// y = silu(LayerNorm(u)): gu from gy (wave per row); u is the Linear output kept by the forward
+void launch_layernorm_silu_bwd(const float* u, const float* gy, const float* w, const float* b, float* gu, int rows, int n, hipStream_t s);
+// gh[row][k] = d log_ratio / d score (score[row]) * w[k]; log_ratio (optional) [rows]
+void launch_ratio_head_bwd(const float* score, const float* w, float* gh, float* log_ratio, int rows, int n, int loss, hipStream_t s);
+// x <- x + (v + gamma g) dt
+void launch_euler_grad(float* x, const float* v, const float* g, size_t n, float gamma, float dt, hipStream_t s);
 
 // ---- guidance / Euler
 struct GuidanceArgs {

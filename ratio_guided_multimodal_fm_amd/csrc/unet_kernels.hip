@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const ConvInArgs a) {
           if (CIN > 1) acc += wr[9 + ky * 3 + kx] * t.y;
           if (CIN > 2) acc += wr[18 + ky * 3 + kx] * t.z;
         }
-      if (a.ep_scale) acc = silu_f(acc * es + eh);
+      if (a.ep_scale) acc = a.ep_nosilu ? acc * es + eh : silu_f(acc * es + eh);
       a.out[(pix0 + k) * a.C0 + c] = acc;
       if (k == hh) pivot = acc;
       const float d = acc - pivot;

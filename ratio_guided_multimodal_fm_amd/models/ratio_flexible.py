@@ -63,3 +63,13 @@ class RatioEstimatorMNISTSVHN(nn.Module):
         if self.loss_type not in ("disc", "rulsif"):
             raise ValueError(f"Unknown loss_type: {self.loss_type}")
         return self._engine.eval(x, y, "log_ratio")
+
+    def grad_log_ratio(self, x, y):
+        """(d log_ratio/dx, d log_ratio/dy): what ``torch.autograd.grad(self.log_ratio(x, y).sum(), (x, y))``
+        returns for the reference module in eval mode -- the quantity of the reference README's "Gradient
+        Log-Ratio" guidance (``README.md:159-164``), which the reference itself never computes.  Hand-written
+        reverse pass on the device (``csrc/ratio_grad.hip``); the parameters themselves get no gradient."""
+        if self.loss_type not in ("disc", "rulsif"):
+            raise ValueError(f"Unknown loss_type: {self.loss_type}")
+        gx, gy, _ = self._engine.grad_log_ratio(x, y)
+        return gx, gy

@@ -26,7 +26,9 @@ def sample_bimodal_guided_mnist_svhn(fm_mnist, fm_svhn, ratio_estimator=None, gu
 
 def main(argv=None):
     p = argparse.ArgumentParser(description='Sample MNIST-SVHN pairs (MI355X)')
-    p.add_argument('--guidance_method', type=str, default='none', choices=['none', 'mc_feng'])
+    p.add_argument('--guidance_method', type=str, default='none', choices=['none', 'mc_feng', 'grad_log_ratio'],
+                   help="'grad_log_ratio' (v + gamma * grad log r, reference README.md:159-164) is this build's extension: "
+                        "the reference CLI accepts 'none' and 'mc_feng' only")
     p.add_argument('--guidance_strength', type=float, default=0.5)
     p.add_argument('--mc_batch_size', type=int, default=256)
     p.add_argument('--loss_type', type=str, default='disc')

@@ -55,6 +55,7 @@ def paired_sampler(fm_x, fm_y, ratio_estimator, guidance_method, guidance_streng
         ratio_estimator.eval()
     dev = _device(device)
     guided = guidance_method == 'mc_feng' and ratio_estimator is not None
+    grad_guided = guidance_method == 'grad_log_ratio' and ratio_estimator is not None
 
     if noise is None:
         x_t = torch.randn(num_samples, *shape_x, device=dev)
@@ -85,6 +86,13 @@ def paired_sampler(fm_x, fm_y, ratio_estimator, guidance_method, guidance_streng
             print(f"  MC ratios: min={mc_ratios.min():.4f}, max={mc_ratios.max():.4f}, "
                   f"mean={mc_ratios.mean():.4f}")
 
+    if grad_guided:
+        # "Gradient Log-Ratio" of the reference README (:159-164): v + gamma * grad log r(x_t, y_t) every step.  The
+        # reference accepts only 'none' / 'mc_feng' and has no code for this mode; see rgfm_sample_pair_grad.
+        if ratio_estimator.loss_type not in ("disc", "rulsif"):
+            raise ValueError(f"Unknown loss_type: {ratio_estimator.loss_type}")
+        _engine.sample_pair_grad(fm_x, fm_y, ratio_estimator, x_t, y_t, num_steps, guidance_strength)
+        return x_t, y_t
     _engine.sample_pair(fm_x, fm_y, x_t, y_t, mc_x1, mc_y1, mc_ratios, num_steps, guidance_strength)
     return x_t, y_t
 

@@ -407,6 +407,26 @@ def gen_sweep200():
     save("sweep200", **out)
 
 
+def gen_ratio_grad():
+    """d log r(x, y) / d(x, y) by torch.autograd on the reference RatioEstimatorMNISTSVHN
+    (ratio_flexible.py:347-385) in eval mode, both loss types, at noise-like and at image-like inputs."""
+    out = {}
+    g = torch.Generator().manual_seed(85)
+    x = torch.randn(3, 1, 32, 32, generator=g)
+    y = torch.randn(3, 3, 32, 32, generator=g)
+    out["x_fp"], out["y_fp"] = n(x.reshape(-1)[:8]), n(y.reshape(-1)[:8])
+    for loss in ("disc", "rulsif"):
+        ref = build(RefRatioMS, ours.RatioEstimatorMNISTSVHN, SEED_W["ratio_ms"])
+        ref.loss_type = loss
+        for tag, scale in (("n", 1.0), ("s", 0.3)):
+            xx = (x * scale).clone().requires_grad_(True)
+            yy = (y * scale).clone().requires_grad_(True)
+            lr = ref.log_ratio(xx, yy)
+            gx, gy = torch.autograd.grad(lr.sum(), (xx, yy))
+            out[f"{loss}_{tag}_lr"], out[f"{loss}_{tag}_gx"], out[f"{loss}_{tag}_gy"] = n(lr.detach()), n(gx), n(gy)
+    save("ratio_grad", **out)
+
+
 def gen_coherence28():
     """MNISTClassifier (src/models/classifier.py) logits on the golden 28x28 pairs.  src/evaluate.py itself
     cannot be imported here (it needs torchvision), so the coherence value is its :84-91 restated on the
@@ -450,9 +470,9 @@ def gen_fm_original():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["embedding", "unet_layers", "ratio", "guidance", "samplers", "coherence", "fm_original", "coherence28", "fp64", "unet_generic", "sweep200"]
+    which = sys.argv[1:] or ["embedding", "unet_layers", "ratio", "guidance", "samplers", "coherence", "fm_original", "coherence28", "fp64", "unet_generic", "sweep200", "ratio_grad"]
     for w in which:
         {"embedding": gen_embedding, "unet_layers": gen_unet_layers, "ratio": gen_ratio,
          "guidance": gen_guidance, "samplers": gen_samplers, "coherence": gen_coherence,
          "fm_original": gen_fm_original, "coherence28": gen_coherence28, "fp64": gen_fp64, "unet_generic": gen_unet_generic,
-         "sweep200": gen_sweep200}[w]()
+         "sweep200": gen_sweep200, "ratio_grad": gen_ratio_grad}[w]()

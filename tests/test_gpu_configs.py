@@ -134,6 +134,60 @@ def test_time_embedding_table_against_reference_fixture(dev):
         assert got.shape == ref.shape and maxdiff(got, ref) < 2e-6, (tag, maxdiff(got, ref))
 
 
+# ------------------------------------------------------------------ gradient log-ratio guidance
+@pytest.mark.parametrize("loss", ["disc", "rulsif"])
+def test_ratio_gradient_vs_autograd_fixture_and_oracle(dev, loss):
+    """d log r / d(x, y) of RatioEstimatorMNISTSVHN on the HIP path (hand-written reverse pass, csrc/ratio_grad.hip)
+    against torch.autograd.grad on the reference module (tests/golden/ratio_grad.npz) and against the oracle on a
+    ragged batch.  Tolerance: relative 1e-4 of the largest gradient entry (fp32 forward + reverse pass)."""
+    from ratio_guided_multimodal_fm_amd import models as M
+    from ratio_guided_multimodal_fm_amd.synth import load_synth
+    g = golden("ratio_grad")
+    rr = load_synth(M.RatioEstimatorMNISTSVHN(loss_type=loss), 16).eval().to(dev)
+    gen = torch.Generator().manual_seed(85)
+    x = torch.randn(3, 1, 32, 32, generator=gen)
+    y = torch.randn(3, 3, 32, 32, generator=gen)
+    for tag, sc in (("n", 1.0), ("s", 0.3)):
+        gx, gy, lr = rr._engine.grad_log_ratio((x * sc).to(dev), (y * sc).to(dev))
+        rx, ry = g[f"{loss}_{tag}_gx"], g[f"{loss}_{tag}_gy"]
+        assert maxdiff(lr.cpu().numpy(), g[f"{loss}_{tag}_lr"]) < 1e-5
+        assert maxdiff(gx.cpu().numpy(), rx) < 1e-4 * np.abs(rx).max(), (tag, maxdiff(gx.cpu().numpy(), rx))
+        assert maxdiff(gy.cpu().numpy(), ry) < 1e-4 * np.abs(ry).max(), (tag, maxdiff(gy.cpu().numpy(), ry))
+        a, b = rr.grad_log_ratio((x * sc).to(dev), (y * sc).to(dev))  # the module-level API
+        assert torch.equal(a, gx) and torch.equal(b, gy)
+    # ragged batch (partial tiles at the 2x2 / 4x4 levels) against the oracle
+    _, br = oracle_net("ratio_ms")
+    xb = torch.randn(7, 1, 32, 32, generator=gen)
+    yb = torch.randn(7, 3, 32, 32, generator=gen)
+    gx, gy, lr = rr._engine.grad_log_ratio(xb.to(dev), yb.to(dev))
+    ox, oy, olr = O.ratio_grad(br, xb.numpy(), yb.numpy(), loss)
+    assert maxdiff(lr.cpu().numpy(), olr) < 1e-5
+    assert maxdiff(gx.cpu().numpy(), ox) < 1e-4 * np.abs(ox).max() and maxdiff(gy.cpu().numpy(), oy) < 1e-4 * np.abs(oy).max()
+    r28 = make_module("ratio28", dev)  # GroupNorm encoders: no reverse pass
+    with pytest.raises(_lib.RgfmError):
+        r28._engine.grad_log_ratio(torch.zeros(1, 1, 28, 28, device=dev), torch.zeros(1, 1, 28, 28, device=dev))
+
+
+def test_grad_log_ratio_sampler_vs_oracle(dev):
+    """guidance_method='grad_log_ratio' (reference README.md:159-164; no reference code exists, so the composition
+    x <- x + (v + gamma grad log r) dt is checked against this build's own oracle: "parity unpinned" for the loop,
+    pinned for the gradient).  gamma 0 must equal the unguided sampler."""
+    from ratio_guided_multimodal_fm_amd.utils.flow_utils import paired_sampler
+    fm, fs, rr = make_module("mnist32", dev), make_module("svhn", dev), make_module("ratio_ms", dev)
+    noise = paired_noise(33, 5, 0, (1, 32, 32), (3, 32, 32))
+    S, gamma = 6, 2.0
+    xs, ys = paired_sampler(fm, fs, rr, "grad_log_ratio", gamma, 5, S, dev, 4, (1, 32, 32), (3, 32, 32), noise=noise, verbose=False)
+    dx, bx = oracle_net("mnist32")
+    dy, by = oracle_net("svhn")
+    _, br = oracle_net("ratio_ms")
+    ox, oy = O.sample_pair_grad(dx, bx, dy, by, br, noise[0].numpy(), noise[1].numpy(), S, gamma)
+    assert maxdiff(xs.cpu().numpy(), ox) < TOL_SAMPLER and maxdiff(ys.cpu().numpy(), oy) < TOL_SAMPLER
+    x0, y0 = paired_sampler(fm, fs, rr, "grad_log_ratio", 0.0, 5, S, dev, 4, (1, 32, 32), (3, 32, 32), noise=noise, verbose=False)
+    xn, yn = paired_sampler(fm, fs, None, "none", 0.0, 5, S, dev, 4, (1, 32, 32), (3, 32, 32), noise=noise, verbose=False)
+    assert maxdiff(x0.cpu().numpy(), xn.cpu().numpy()) < 1e-6 and maxdiff(y0.cpu().numpy(), yn.cpu().numpy()) < 1e-6
+    assert maxdiff(xs.cpu().numpy(), xn.cpu().numpy()) > 1e-5  # (the guidance does something)
+
+
 # ------------------------------------------------------------------ checkpoints and CLIs (SURVEY 8f row 2)
 def _write_checkpoints(tmp_path):
     """The files the reference's trainers write, from synthetic weights: dict format for the two flow nets
