@@ -141,7 +141,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2_kernel(const ConvArgs a,
       const int c = n0 + nt * 32 + l31p;
       float v = a.bias[c];
       if (a.res_mode == 2) v += a.skip_bias[c];
-      if (a.temb && sample_ok) v += a.temb[(size_t)(a.temb_per_row ? bw : 0) * a.temb_stride + c];
+      if (a.temb && sample_ok) v += a.temb[((size_t)(a.temb_per_row ? bw : 0) + (a.step_ptr ? (size_t)*a.step_ptr : 0)) * a.temb_stride + c];
       add0[nt] = v * qmain;  // the accumulators hold q x the true sums
     }
     if (a.res_mode == 1) {

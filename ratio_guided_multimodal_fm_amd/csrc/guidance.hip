@@ -23,7 +23,18 @@ constexpr int GLD = GD + 4;   // LDS row stride (floats): conflict-free b128 row
 // (row, MC sample) pairs and writes the fp64 partial sum; guid_apply adds the slices (fp64 sums of fp32 chunk
 // partials are exact, so the slicing does not change a bit) -- 4x the workgroups of an unsliced launch at the
 // benchmark shape, where 16 x 8 tiles would leave half of the 256 CUs idle on a kernel that nothing overlaps.
-__global__ __launch_bounds__(256) void guid_logp_kernel(const GuidanceArgs a) {
+// the step's scalars: launch arguments, or (hipGraph replay) the schedule row of the device-side step counter
+__device__ __forceinline__ GuidanceArgs with_schedule(const GuidanceArgs& in) {
+  GuidanceArgs a = in;
+  if (in.sched) {
+    const float* q = in.sched + 4 * (size_t)*in.step_ptr;
+    a.tf = q[0], a.s2 = q[1], a.cden = q[2];
+  }
+  return a;
+}
+
+__global__ __launch_bounds__(256) void guid_logp_kernel(const GuidanceArgs a_in) {
+  const GuidanceArgs a = with_schedule(a_in);
   __shared__ __attribute__((aligned(16))) float sx[32 * GLD];
   __shared__ __attribute__((aligned(16))) float sm[32 * GLD];
   const int tid = threadIdx.x;
@@ -115,7 +126,8 @@ __device__ __forceinline__ float wave_max_g(float v) {
 }
 
 // grid (ceil(B/4), ceil(D/1024)); one launch per modality (part).
-__global__ __launch_bounds__(256) void guid_apply_kernel(const GuidanceArgs a, int part) {
+__global__ __launch_bounds__(256) void guid_apply_kernel(const GuidanceArgs a_in, int part) {
+  const GuidanceArgs a = with_schedule(a_in);
   extern __shared__ __attribute__((aligned(16))) float sw[];  // [4][N]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int N = a.N;
@@ -228,6 +240,25 @@ __global__ void euler_kernel(float* x, const float* v, size_t n, float dt) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     x[i] = __fadd_rn(x[i], __fmul_rn(v[i], dt));
 }
+
+// Per-step scalars of the guidance block for steps step_begin .. step_begin + ns - 1: the reference's Python-double
+// arithmetic (sample_mnist_svhn.py:115,127,135,159: t = step * dt, sigma_t = 1 - t + eps), the same IEEE double
+// operations the host path performs, rounded to fp32 where a tensor op consumes them.
+__global__ void guid_schedule_kernel(float* sched, int step_begin, int ns, int num_steps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ns) return;
+  const double dtd = 1.0 / (double)num_steps;
+  const double t = (double)(step_begin + i) * dtd;
+  const double eps = 1e-3;
+  const double sigma_t = 1.0 - t + eps;
+  sched[4 * i] = (float)t, sched[4 * i + 1] = (float)(sigma_t * sigma_t), sched[4 * i + 2] = (float)(1.0 - t + eps), sched[4 * i + 3] = 0.f;
+}
+void launch_guid_schedule(float* sched, int step_begin, int ns, int num_steps, hipStream_t s) {
+  hipLaunchKernelGGL(guid_schedule_kernel, dim3((ns + 255) / 256), dim3(256), 0, s, sched, step_begin, ns, num_steps);
+}
+
+__global__ void step_inc_kernel(int* step) { *step += 1; }
+void launch_step_inc(int* step, hipStream_t s) { hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, s, step); }
 
 void launch_euler(float* x, const float* v, size_t n, float dt, hipStream_t s) {
   const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);

@@ -234,6 +234,8 @@ struct Modes {
   int conv = CONV_ARITH_HX2;
   bool overlap = true, fuse_fin = true, gn_consumer = true;
   bool pipelined = true;  // RGFM_HX2P=0: the fp16 convs on conv_mfma_hx2_kernel only (A/B switch)
+  bool graph = false;     // RGFM_GRAPH=1: the guided steps of the paired U-Net loop replayed from one captured hipGraph
+                          // (bit-identical; measured 0.995-1.002x of the kernel-by-kernel path: the host is not the bottleneck)
 };
 Modes g_modes;
 void refresh_modes() {
@@ -249,6 +251,8 @@ void refresh_modes() {
   m.gn_consumer = !(e && strcmp(e, "table") == 0);
   e = getenv("RGFM_HX2P");
   m.pipelined = !(e && e[0] == '0');
+  e = getenv("RGFM_GRAPH");
+  m.graph = e && e[0] == '1';
   g_modes = m;
 }
 
@@ -261,7 +265,15 @@ struct DevState {
   int num_cus = 256;
   hipStream_t side = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
+  // the legacy default stream cannot be captured: a caller on it has its graph-replayed loop run on `main`,
+  // forked from / joined back into the default stream with these events
+  hipStream_t main = nullptr;
+  hipEvent_t main_fork = nullptr, main_join = nullptr;
   unsigned* range_flag = nullptr;
+  // hipGraphs of earlier sampler calls that may still be executing: destroyed once `graph_done` (recorded behind the
+  // latest replay) has completed
+  hipEvent_t graph_done = nullptr;
+  std::vector<std::pair<hipGraphExec_t, hipGraph_t>> graphs;
 };
 DevState g_dev[MAX_DEVICES];
 
@@ -285,6 +297,10 @@ int ensure_init() {
     HIP_TRY(hipStreamCreateWithFlags(&d.side, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&d.fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&d.join, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&d.graph_done, hipEventDisableTiming));
+    HIP_TRY(hipStreamCreateWithFlags(&d.main, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&d.main_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&d.main_join, hipEventDisableTiming));
     HIP_TRY(hipMalloc(&d.range_flag, 256));
     HIP_TRY(hipMemset(d.range_flag, 0, 256));
     d.init = true;
@@ -535,6 +551,7 @@ struct UNetRun {
   int temb_per_row;
   bool dry;
   unsigned* fin_counter = nullptr;  // [B] arrival counters (zero between launches) or null: separate gn_finalize
+  const int* step_ptr = nullptr;    // device-side step counter: temb_row is then the table's first row (ConvArgs::step_ptr)
   PendingConv pend{};
 
   Tensor new_tensor(int C, int S) {
@@ -583,6 +600,7 @@ struct UNetRun {
     c.wpk3 = h->packed3 + w.w_bx3;
     c.bias = h->params + w.b;
     c.temb = temb, c.temb_stride = h->temb_total, c.temb_per_row = temb_per_row;
+    c.step_ptr = temb ? step_ptr : nullptr;
     c.res_mode = res_mode;
     if (res_mode) {
       c.res0 = r0->data, c.res1 = r1 ? r1->data : nullptr;
@@ -955,19 +973,27 @@ extern "C" int rgfm_guidance_workspace_bytes(int batch, int n_mc, size_t* bytes)
 }
 
 namespace {
+// The step's scalars of the guidance block: Python-double arithmetic of the reference
+// (sample_mnist_svhn.py:115,127,135,159,170), rounded to fp32 where a tensor op consumes it.
+void guidance_scalars(double t, float* tf, float* s2, float* cden) {
+  const double eps = 1e-3;
+  const double sigma_t = 1.0 - t + eps;
+  *tf = (float)t, *s2 = (float)(sigma_t * sigma_t), *cden = (float)(1.0 - t + eps);
+}
+
 int guidance_launch(const float* x, const float* y, float* vx, float* vy, const float* mx, const float* my,
                     const float* r, int B, int N, int dx, int dy, double t, double gamma, float* logp,
-                    float* weights_out, float* xs, float* ys, float dt, hipStream_t s) {
+                    float* weights_out, float* xs, float* ys, float dt, hipStream_t s, const float* sched = nullptr,
+                    const int* step_ptr = nullptr) {
   if (dx % 4 || dy % 4) return fail(RGFM_EINVAL, "flattened image sizes must be multiples of 4");
   if ((size_t)4 * N * sizeof(float) > 64 * 1024) return fail(RGFM_EINVAL, "n_mc too large (max 4096)");
   // Python-double scalar arithmetic of the reference (sample_mnist_svhn.py:115,127,135,159,170),
   // rounded to fp32 where a tensor op consumes it.
-  const double eps = 1e-3;
-  const double sigma_t = 1.0 - t + eps;
   GuidanceArgs a{};
   a.x = x, a.y = y, a.vx = vx, a.vy = vy, a.mc_x1 = mx, a.mc_y1 = my, a.mc_ratios = r;
   a.B = B, a.N = N, a.dx = dx, a.dy = dy;
-  a.tf = (float)t, a.s2 = (float)(sigma_t * sigma_t), a.cden = (float)(1.0 - t + eps);
+  guidance_scalars(t, &a.tf, &a.s2, &a.cden);
+  a.sched = sched, a.step_ptr = sched ? step_ptr : nullptr;
   a.g1 = (float)(1.0 - gamma), a.g2 = (float)gamma;
   a.dist = reinterpret_cast<double*>(logp), a.weights_out = weights_out, a.x_state = xs, a.y_state = ys, a.dt = dt;
   a.slice_len = 1024;  // 1024-element slices unless that needs more than RGFM_GUID_SLICES of them
@@ -1009,10 +1035,16 @@ namespace {
 // Shared Euler loop of paired_sampler (src/utils/flow_utils.py:186-278 with the guidance of
 // src/sample_mnist_svhn.py:117-175): eval_x / eval_y enqueue one velocity-net evaluation of step i
 // on the given stream, writing the raw velocity (guided steps) or the fused Euler update.
+// Graph replay (U-Net pairs, RGFM_GRAPH=1; never with active kernel timers): every guided step enqueues the
+// same ~135 launches with the same arguments except the time-table row and three guidance scalars.  Those are read
+// on the device through a step counter (`gstate`: [0] the counter, [64..] the per-step scalars), so the first guided
+// step is captured once -- both streams, fork and join included -- into a hipGraph and every guided step is one
+// hipGraphLaunch.  Results are bit-identical to the kernel-by-kernel path (same kernels, same arguments).
 template <class EvalX, class EvalY>
 int pair_loop(EvalX&& eval_x, EvalY&& eval_y, float* x_inout, float* y_inout, const float* mc_x1,
               const float* mc_y1, const float* mc_ratios, int n_mc, int batch, int num_steps, double gamma,
-              int step_begin, int ns, int dx, int dy, float* vx, float* vy, float* logp, hipStream_t s) {
+              int step_begin, int ns, int dx, int dy, float* vx, float* vy, float* logp, hipStream_t caller,
+              float* gstate = nullptr) {
   const double dtd = 1.0 / (double)num_steps;
   const float dt = (float)dtd;
   // The two velocity nets of a step are independent (reference :119-121): the second one runs on a
@@ -1024,25 +1056,72 @@ int pair_loop(EvalX&& eval_x, EvalY&& eval_y, float* x_inout, float* y_inout, co
   const bool overlap = g_modes.overlap;
   hipStream_t side = ds->side;
   hipEvent_t ev_fork = ds->fork, ev_join = ds->join;
-  for (int i = 0; i < ns; ++i) {
-    const double t = (double)(step_begin + i) * dtd;
-    const bool guided = n_mc > 0 && t > 1e-3;  // `t > eps` test of the reference (:124)
+  const bool use_graph = gstate && g_modes.graph && !g_prof.on && n_mc > 0 && ns >= 4;
+  hipStream_t s = caller;
+  if (use_graph && caller == nullptr) {  // (see DevState::main)
+    s = ds->main;
+    HIP_TRY(hipEventRecord(ds->main_fork, caller));
+    HIP_TRY(hipStreamWaitEvent(s, ds->main_fork, 0));
+  }
+  int* step_dev = nullptr;
+  float* sched_dev = nullptr;
+  if (use_graph) {
+    // graphs of earlier calls: release them once the device is past their last replay
+    if (!ds->graphs.empty() && hipEventQuery(ds->graph_done) == hipSuccess) {
+      for (auto& g : ds->graphs) (void)hipGraphExecDestroy(g.first), (void)hipGraphDestroy(g.second);
+      ds->graphs.clear();
+    }
+    step_dev = reinterpret_cast<int*>(gstate);
+    sched_dev = gstate + 64;
+    HIP_TRY(hipMemsetAsync(step_dev, 0, 256, s));
+    launch_guid_schedule(sched_dev, step_begin, ns, num_steps, s);
+  }
+  auto one_step = [&](int i, bool guided) -> int {
     hipStream_t sy = overlap ? side : s;
     if (overlap) {
       HIP_TRY(hipEventRecord(ev_fork, s));
       HIP_TRY(hipStreamWaitEvent(side, ev_fork, 0));
     }
-    int rc = eval_y(i, sy, guided ? vy : nullptr, guided ? nullptr : y_inout, dt);
+    int rc = eval_y(i, sy, guided ? vy : nullptr, guided ? nullptr : y_inout, dt, step_dev);
     if (rc) return rc;
     if (overlap) HIP_TRY(hipEventRecord(ev_join, side));
-    rc = eval_x(i, s, guided ? vx : nullptr, guided ? nullptr : x_inout, dt);
+    rc = eval_x(i, s, guided ? vx : nullptr, guided ? nullptr : x_inout, dt, step_dev);
     if (rc) return rc;
     if (overlap) HIP_TRY(hipStreamWaitEvent(s, ev_join, 0));
     if (guided) {
+      const double t = (double)(step_begin + i) * dtd;
       rc = guidance_launch(x_inout, y_inout, vx, vy, mc_x1, mc_y1, mc_ratios, batch, n_mc, dx, dy, t, gamma, logp,
-                           nullptr, x_inout, y_inout, dt, s);
+                           nullptr, x_inout, y_inout, dt, s, sched_dev, step_dev);
       if (rc) return rc;
     }
+    if (step_dev) launch_step_inc(step_dev, s);
+    return RGFM_OK;
+  };
+  hipGraphExec_t exec = nullptr;
+  for (int i = 0; i < ns; ++i) {
+    const double t = (double)(step_begin + i) * dtd;
+    const bool guided = n_mc > 0 && t > 1e-3;  // `t > eps` test of the reference (:124)
+    if (use_graph && guided) {
+      if (!exec) {
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+        const int rc = one_step(i, true);
+        const hipError_t ce = hipStreamEndCapture(s, &graph);
+        if (rc) return rc;
+        if (ce != hipSuccess || !graph) return fail(RGFM_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+        HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        ds->graphs.push_back({exec, graph});
+      }
+      HIP_TRY(hipGraphLaunch(exec, s));
+      continue;
+    }
+    const int rc = one_step(i, guided);
+    if (rc) return rc;
+  }
+  if (exec) HIP_TRY(hipEventRecord(ds->graph_done, s));
+  if (s != caller) {
+    HIP_TRY(hipEventRecord(ds->main_join, s));
+    HIP_TRY(hipStreamWaitEvent(caller, ds->main_join, 0));
   }
   HIP_TRY(hipGetLastError());
   return RGFM_OK;
@@ -1059,6 +1138,7 @@ extern "C" int rgfm_sample_pair_workspace_bytes(const rgfm_unet* hx, const rgfm_
   size_t total = table_bytes(hx, 4096) + table_bytes(hy, 4096) + ex + ey + 2 * counter_bytes(batch);  // the two nets run concurrently
   total += ((batch * dx * 4 + 255) & ~(size_t)255) + ((batch * dy * 4 + 255) & ~(size_t)255);
   total += guid_scratch_bytes(batch, n_mc);
+  total += 256 + (size_t)4096 * 4 * sizeof(float);  // step counter + per-step guidance scalars (graph replay)
   *bytes = total;
   return RGFM_OK;
 }
@@ -1090,26 +1170,28 @@ extern "C" int rgfm_sample_pair(rgfm_unet* hx, rgfm_unet* hy, float* x_inout, fl
   float* logp = b.f(guid_scratch_bytes(batch, n_mc) / sizeof(float));
   unsigned* cnt_x = reinterpret_cast<unsigned*>(b.f(batch));
   unsigned* cnt_y = reinterpret_cast<unsigned*>(b.f(batch));
+  float* gstate = b.f(64 + (size_t)4096 * 4);
   HIP_TRY(hipMemsetAsync(cnt_x, 0, (size_t)batch * sizeof(unsigned), s));
   HIP_TRY(hipMemsetAsync(cnt_y, 0, (size_t)batch * sizeof(unsigned), s));
   launch_time_table(hx, nullptr, num_steps, step_begin, ns, tx, s);
   launch_time_table(hy, nullptr, num_steps, step_begin, ns, ty, s);
   const size_t mark_x = b.off;
   const size_t mark_y = mark_x + unet_eval_bytes(hx, batch);
-  auto eval_x = [&](int i, hipStream_t st, float* v_out, float* x_state, float dt) {
+  // (step: the device-side step counter of the graph-replay path -- the time-table row is then chosen on the device)
+  auto eval_x = [&](int i, hipStream_t st, float* v_out, float* x_state, float dt, const int* step) {
     b.off = mark_x;
-    UNetRun r{hx, batch, &b, st, tx + (size_t)i * hx->temb_total, 0, false};
-    r.fin_counter = cnt_x;
+    UNetRun r{hx, batch, &b, st, step ? tx : tx + (size_t)i * hx->temb_total, 0, false};
+    r.fin_counter = cnt_x, r.step_ptr = step;
     return r.run(x_inout, v_out, x_state, dt);
   };
-  auto eval_y = [&](int i, hipStream_t st, float* v_out, float* y_state, float dt) {
+  auto eval_y = [&](int i, hipStream_t st, float* v_out, float* y_state, float dt, const int* step) {
     b.off = mark_y;
-    UNetRun r{hy, batch, &b, st, ty + (size_t)i * hy->temb_total, 0, false};
-    r.fin_counter = cnt_y;
+    UNetRun r{hy, batch, &b, st, step ? ty : ty + (size_t)i * hy->temb_total, 0, false};
+    r.fin_counter = cnt_y, r.step_ptr = step;
     return r.run(y_inout, v_out, y_state, dt);
   };
   return pair_loop(eval_x, eval_y, x_inout, y_inout, mc_x1, mc_y1, mc_ratios, n_mc, batch, num_steps, gamma,
-                   step_begin, ns, dx, dy, vx, vy, logp, s);
+                   step_begin, ns, dx, dy, vx, vy, logp, s, gstate);
 }
 
 // ================================================================== ratio estimators
@@ -2069,13 +2151,13 @@ extern "C" int rgfm_fmnet_sample_pair(rgfm_fmnet* hx, rgfm_fmnet* hy, float* x_i
   HIP_TRY(hipMemsetAsync(cnt_y, 0, (size_t)batch * sizeof(unsigned), s));
   const size_t mark_x = b.off;
   const size_t mark_y = mark_x + fm_eval_bytes(hx, batch);
-  auto eval_x = [&](int i, hipStream_t st, float* v_out, float* x_state, float dt) {
+  auto eval_x = [&](int i, hipStream_t st, float* v_out, float* x_state, float dt, const int*) {
     b.off = mark_x;
     FmRun r{hx, batch, &b, st, false, nullptr, 1, num_steps, step_begin + i};
     r.fin_counter = cnt_x;
     return r.run(x_inout, v_out, x_state, dt);
   };
-  auto eval_y = [&](int i, hipStream_t st, float* v_out, float* y_state, float dt) {
+  auto eval_y = [&](int i, hipStream_t st, float* v_out, float* y_state, float dt, const int*) {
     b.off = mark_y;
     FmRun r{hy, batch, &b, st, false, nullptr, 1, num_steps, step_begin + i};
     r.fin_counter = cnt_y;

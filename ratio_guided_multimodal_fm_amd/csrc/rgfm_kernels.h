@@ -102,6 +102,8 @@ struct ConvArgs {
   const float* temb; // time-embedding add: temb[(per_row ? b : 0) * temb_stride + c]; null = none
   int temb_stride;
   int temb_per_row;
+  const int* step_ptr;  // optional device word: the row of the time table is *step_ptr (+ b when temb_per_row): lets
+                        // one captured launch sequence (hipGraph) serve every Euler step
   // residual: res_mode 0 none; 1 identity (res0 NHWC [.., Cout]); 2 fused 1x1 conv over cat(res0, res1)
   int res_mode;
   const float* res0;
@@ -278,6 +280,9 @@ struct GuidanceArgs {
   float tf, s2, cden, g1, g2;
   double* dist;        // [nsx + nsy][B][N] scratch: sliced squared distances (guid_logp -> guid_apply)
   int slice_len, nsx, nsy;  // D-slices per modality (<= RGFM_GUID_SLICES in all)
+  // optional (hipGraph replay): the step's scalars {tf, s2, cden, -} come from sched[4 * *step_ptr] instead of the fields
+  const float* sched;
+  const int* step_ptr;
   float* weights_out;  // optional [B][N]
   float* x_state;      // optional fused Euler: x_state += dt * blended
   float* y_state;
@@ -287,5 +292,7 @@ constexpr int RGFM_GUID_SLICES = 8;
 void launch_guid_logp(const GuidanceArgs& a, hipStream_t s);   // distances -> GuidanceArgs::dist
 void launch_guid_apply(const GuidanceArgs& a, hipStream_t s);  // weights, guided velocity, blend (+ Euler)
 void launch_euler(float* x, const float* v, size_t n, float dt, hipStream_t s);
+void launch_step_inc(int* step, hipStream_t s);  // *step += 1
+void launch_guid_schedule(float* sched, int step_begin, int ns, int num_steps, hipStream_t s);  // [ns][4] = {tf, s2, cden, 0}
 
 }  // namespace rgfm

@@ -134,6 +134,40 @@ def test_time_embedding_table_against_reference_fixture(dev):
         assert got.shape == ref.shape and maxdiff(got, ref) < 2e-6, (tag, maxdiff(got, ref))
 
 
+def test_graph_replay_is_bitwise_the_eager_path(dev, monkeypatch):
+    """The guided Euler loop as ONE captured hipGraph replayed per step (RGFM_GRAPH=1) against the kernel-by-kernel path
+    (default): same kernels, same arguments (the time-table row and the step's guidance scalars are read on the
+    device through a step counter), so the results must be bit-identical -- also for a step range that does not
+    start at 0 and with the two nets on one stream."""
+    fm, fs, rr = make_module("mnist32", dev), make_module("svhn", dev), make_module("ratio_ms", dev)
+    B, N, S = 9, 6, 12
+    x0, y0, mx0, my0 = (t.to(dev) for t in paired_noise(14, B, N, (1, 32, 32), (3, 32, 32)))
+    mx1, my1 = mx0.clone(), my0.clone()
+    _engine.sample_two_streams(fm, mx1, fs, my1, S)
+    r = rr._engine.eval(mx1, my1, "ratio")
+    for env, (sb, se) in (({}, (0, S)), ({}, (3, S)), ({"RGFM_OVERLAP": "0"}, (0, S))):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        res = {}
+        for graph in ("1", "0"):
+            monkeypatch.setenv("RGFM_GRAPH", graph)
+            xa, ya = x0.clone(), y0.clone()
+            _engine.sample_pair(fm, fs, xa, ya, mx1, my1, r, S, 0.7, sb, se)
+            res[graph] = (xa.clone(), ya.clone())
+        assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][1], res["0"][1]), (env, sb)
+        for k in env:
+            monkeypatch.delenv(k)
+    monkeypatch.delenv("RGFM_GRAPH")
+    # and against the oracle (12 steps from 0)
+    dx, bx = oracle_net("mnist32")
+    dy, by = oracle_net("svhn")
+    xa, ya = x0.clone(), y0.clone()
+    _engine.sample_pair(fm, fs, xa, ya, mx1, my1, r, S, 0.7)
+    ox, oy = O.sample_pair(dx, bx, dy, by, x0.cpu().numpy(), y0.cpu().numpy(), mx1.cpu().numpy(), my1.cpu().numpy(),
+                           r.cpu().numpy(), S, 0.7)
+    assert maxdiff(xa.cpu().numpy(), ox) < TOL_SAMPLER and maxdiff(ya.cpu().numpy(), oy) < TOL_SAMPLER
+
+
 # ------------------------------------------------------------------ gradient log-ratio guidance (SURVEY 8f row 4)
 @pytest.mark.parametrize("loss", ["disc", "rulsif"])
 def test_ratio_gradient_vs_autograd_fixture_and_oracle(dev, loss):
