@@ -55,7 +55,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
   long long pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   PPROF_T(tk0);
-  const int abytes = NA * a.halo_px * HRW;     // one halo buffer
+  const int abytes = (NA * a.halo_px + 1) * HRW;  // one halo buffer (+ a pad record: the store target of lanes past the halo)
   char* const sB = smemp + 2 * abytes;         // two unit-sized weight buffers
   float* const sTab = reinterpret_cast<float*>(sB + 2 * UB);  // [NA * spt][cin][2] S_A x (scale, shift)
 
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
   if (rows_valid > g.th) rows_valid = g.th;
   const int nvalid = rows_valid * W;
 
-  int arec[2];
+  int arec[2], aofs[2][3][2];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int p = 64 * seg + 32 * mt + l31p;
@@ -110,13 +110,23 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
     }
     const int r = (int)(__umul24((unsigned)q, mW) >> 16), x = q - r * W;
     arec[mt] = (PAIRN ? 0 : grp) * a.halo_px + (s * HR + r) * WR + x;
+    // byte offset of this lane's fragment of tap (ky = 0, kx) inside a halo buffer, plane h / l: in THIS kernel the
+    // four 16-byte slots of a halo record are swizzled with its halo column, (x >> 2) & 3 -- 16 consecutive
+    // columns still cover all 16 slot columns of the bank row, and the term no longer depends on the kernel row,
+    // so the six offsets are computed once per block instead of per tap
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int sw = ((x + kx) >> 2) & 3;
+      aofs[mt][kx][0] = (arec[mt] + kx) * HRW + ((hp_ ^ sw) & 3) * 16;
+      aofs[mt][kx][1] = (arec[mt] + kx) * HRW + (((2 + hp_) ^ sw) & 3) * 16;
+    }
   }
   int bbase[NT], bsw[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int rec = (PAIRN ? grp : 0) * NBLK + nt * 32 + l31p;
-    bbase[nt] = rec * HRW;  // + hswz(rec, plane, hp_): NBLK * NG is a multiple of 16, so the swizzle does not depend on the tap
-    bsw[nt] = (rec >> 2) & 3;
+    bbase[nt] = rec * HRW + ((hp_ ^ (rec >> 2)) & 3) * 16;  // plane h (NBT is a multiple of 16: the swizzle does not depend on the tap)
+    bsw[nt] = rec * HRW + (((2 + hp_) ^ (rec >> 2)) & 3) * 16;  // plane l
   }
 
   const int bw = (g.spt == 1) ? b0 : b0 + seg;
@@ -166,14 +176,18 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
   // ---- per-item decode, once: source pixel offset, LDS destination, validity bit, scale/shift slot
   const int q4 = tid & 3;
   const int nA = a.halo_px * 4;
-  int poff[MAXIT], adst[MAXIT];
-  unsigned okmask = 0u, inmask = 0u, smask = 0u;
+  // per item: source pixel offset; LDS destination (plane h; plane l: ^ 32; lanes past the halo: a trash slot, so the
+  // staging code has no per-lane branches); byte offset of its scale/shift pairs in the table -- out-of-image /
+  // out-of-batch items point at an all-zero row behind the table, which makes silu(0 x + 0) = 0 the zero padding
+  int poff[MAXIT], adst[MAXIT], trow[MAXIT];
+  unsigned okmask = 0u;
+  const int nrows_tab = NA * g.spt;  // table rows (+ the zero row)
   {
     const int per = HR * WR;
 #pragma unroll
     for (int j = 0; j < MAXIT; ++j) {
       const int it = tid + 512 * j;
-      poff[j] = 0, adst[j] = 0;
+      poff[j] = 0, adst[j] = NA * a.halo_px * HRW + (q4 >> 1) * 16 + (q4 & 1) * 8, trow[j] = (nrows_tab * (a.C0 + a.C1) + 4 * q4) * 8;
       if (it < NA * nA) {
         const int ga = (NA == 2 && it >= nA) ? 1 : 0;
         const int ita = it - ga * nA;
@@ -200,12 +214,11 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
         }
         ok = ok && (b < a.B);
         const int rec = ga * a.halo_px + hp;
-        adst[j] = (int)__umul24((unsigned)rec, HRW) + hswz(rec, 0, q4 >> 1) + (q4 & 1) * 8;  // plane l: ^ 32
-        inmask |= 1u << j;
+        adst[j] = (int)__umul24((unsigned)rec, HRW) + ((((q4 >> 1) ^ (hx >> 2)) & 3) * 16) + (q4 & 1) * 8;  // plane l: ^ 32
         if (ok) {
           poff[j] = (int)__umul24(__umul24((unsigned)b, (unsigned)a.Hin) + (unsigned)y, (unsigned)a.Win) + x;  // < 2^24 pixels
           okmask |= 1u << j;
-          smask |= (unsigned)(ga * 4 + s) << (3 * j);
+          trow[j] = ((ga * g.spt + s) * (a.C0 + a.C1) + 4 * q4) * 8;
         }
       }
     }
@@ -221,7 +234,10 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
   const char* wsk = reinterpret_cast<const char*>(a.wskiph) + (size_t)blockIdx.y * nskip * TAPB;
 
   f32x4 ra[MAXIT], rb[NB];
-  float amax = 0.f;  // max |a'| this thread has staged (range flag)
+  // range flag: the largest |fp16| (as a bit pattern, per 16-bit half) this thread has stored; >= 0x7800 is |a'| >= 32768
+  typedef unsigned short hx_u16x2 __attribute__((ext_vector_type(2)));
+  hx_u16x2 hmax = {0, 0};
+  const int nitems = (NA * nA + 511) >> 9;  // items that exist for at least one thread (block-uniform)
 
   // raw fp32 fetch of item j of chunk ch
   auto issue_a = [&](int ch, int j) {
@@ -238,30 +254,28 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
     }
     ra[j] = *(const hx_gf32x4*)(src + (size_t)(__umul24((unsigned)poff[j], (unsigned)cs) + (unsigned)(cc + q4 * 4)));
   };
-  // GroupNorm + SiLU + split + store of item j of chunk ch into halo buffer ch & 1
+  // GroupNorm + SiLU + split + store of item j of chunk ch into halo buffer ch & 1 (branch-free per lane)
   auto commit_a = [&](int ch, int j) {
-    if (!((inmask >> j) & 1u)) return;
-    const bool skip = ch >= nmain;
-    const bool xform = !skip && a.gn_stats0 != nullptr;
+    const bool xform = ch < nmain && a.gn_stats0 != nullptr;
     f32x4 v = ra[j];
-    const bool okj = (okmask >> j) & 1u;
     if (xform) {
-      const int s = (smask >> (3 * j)) & 7u;
-      const float* ep = sTab + ((((s >> 2) * g.spt + (s & 3)) * cin + ch * KC + q4 * 4) * 2);
+      const char* ep = reinterpret_cast<const char*>(sTab) + ch * (KC * 8) + trow[j];
       const f32x4 e0 = *reinterpret_cast<const f32x4*>(ep);
-      const f32x4 e1 = *reinterpret_cast<const f32x4*>(ep + 4);
-      v.x = silu_scaled(e0.x * v.x + e0.y);
-      v.y = silu_scaled(e0.z * v.y + e0.w);
-      v.z = silu_scaled(e1.x * v.z + e1.y);
-      v.w = silu_scaled(e1.z * v.w + e1.w);
+      const f32x4 e1 = *reinterpret_cast<const f32x4*>(ep + 16);
+      v.x = silu_scaled(fmaf(e0.x, v.x, e0.y));
+      v.y = silu_scaled(fmaf(e0.z, v.y, e0.w));
+      v.z = silu_scaled(fmaf(e1.x, v.z, e1.y));
+      v.w = silu_scaled(fmaf(e1.z, v.w, e1.w));
     } else {
-      v = v * HX_SA;
+      const float sa = ((okmask >> j) & 1u) ? HX_SA : 0.f;
+      v.x *= sa, v.y *= sa, v.z *= sa, v.w *= sa;
     }
-    v.x = okj ? v.x : 0.f, v.y = okj ? v.y : 0.f, v.z = okj ? v.z : 0.f, v.w = okj ? v.w : 0.f;
-    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     unsigned h0, l0, h1, l1;
     hsplit2(v.x, v.y, h0, l0);
     hsplit2(v.z, v.w, h1, l1);
+    const unsigned m = 0x7fff7fffu;
+    hmax = __builtin_elementwise_max(hmax, __builtin_bit_cast(hx_u16x2, h0 & m));
+    hmax = __builtin_elementwise_max(hmax, __builtin_bit_cast(hx_u16x2, h1 & m));
     const hx_u32x2 ph = {h0, h1}, pl = {l0, l1};
     char* base = smemp + (ch & 1) * abytes;
     *reinterpret_cast<hx_u32x2*>(base + adst[j]) = ph;
@@ -349,37 +363,40 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
     // (visible to every wave after the barrier that opens commit(0))
   }
 
+  if (a.gn_stats0)  // the all-zero row of the padding items
+    for (int i = tid; i < 2 * (a.C0 + a.C1); i += 512) sTab[nrows_tab * (a.C0 + a.C1) * 2 + i] = 0.f;
   __syncthreads();  // the scale/shift table is complete
   // ---- pipeline fill: halo of chunk 0 and weights of unit 0 in LDS, raw halo of chunk 1 and weights of unit 1 in registers
 #pragma unroll
-  for (int j = 0; j < MAXIT; ++j) issue_a(0, j);
+  for (int j = 0; j < MAXIT; ++j)
+    if (j < nitems) issue_a(0, j);
   issue_b(0);
 #pragma unroll
-  for (int j = 0; j < MAXIT; ++j) commit_a(0, j);
+  for (int j = 0; j < MAXIT; ++j)
+    if (j < nitems) commit_a(0, j);
   commit_b(0);
 #pragma unroll
-  for (int j = 0; j < MAXIT; ++j) issue_a(1, j);
+  for (int j = 0; j < MAXIT; ++j)
+    if (j < nitems) issue_a(1, j);
   issue_b(1);
   __syncthreads();
   PPROF_T(tk1);
   PPROF_ADD(grp * 4 + 0, tk0, tk1);
 
-  // one tap: fragments of this wave's 2 pixel tiles x NT channel tiles, 3 MFMAs per tile pair
-  auto tap = [&](const char* sAc, const char* sBu, int toff, int boff) {
+  // one tap (kernel column KX of the row at byte offset `rowoff`): fragments of this wave's 2 pixel tiles x NT channel
+  // tiles, 3 MFMAs per tile pair
+  auto tap = [&](const char* sArow, const char* sBt, auto kx_tag) {
+    constexpr int KX = decltype(kx_tag)::value;
     f16x8 af[2][2], bf[NT][2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      const int rec = arec[mt] + toff;
-      const char* pa = sAc + rec * HRW;
-      const int o0 = ((hp_ ^ (rec >> 2)) & 3) * 16;  // slot of (plane h, half hp_); plane l: ^ 32
-      af[mt][0] = *reinterpret_cast<const f16x8*>(pa + o0);
-      af[mt][1] = *reinterpret_cast<const f16x8*>(pa + (o0 ^ 32));
+      af[mt][0] = *reinterpret_cast<const f16x8*>(sArow + aofs[mt][KX][0]);
+      af[mt][1] = *reinterpret_cast<const f16x8*>(sArow + aofs[mt][KX][1]);
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const int o0 = ((hp_ ^ bsw[nt]) & 3) * 16;
-      bf[nt][0] = *reinterpret_cast<const f16x8*>(sBu + bbase[nt] + boff + o0);
-      bf[nt][1] = *reinterpret_cast<const f16x8*>(sBu + bbase[nt] + boff + (o0 ^ 32));
+      bf[nt][0] = *reinterpret_cast<const f16x8*>(sBt + bbase[nt]);
+      bf[nt][1] = *reinterpret_cast<const f16x8*>(sBt + bsw[nt]);
     }
     constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};  // a_l w_h, a_h w_l, a_h w_h
 #pragma unroll
@@ -390,49 +407,65 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
         for (int nt = 0; nt < NT; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt][PA[q]], bf[nt][PB[q]], acc[mt][nt], 0, 0, 0);
   };
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+  using K2 = std::integral_constant<int, 2>;
 
-  // staging work of unit g = (chunk c, slice u; u < 0: a one-tap unit, every item): weights of unit g + 1 -> LDS,
-  // weights of unit g + 2 -> registers; halo items j % 3 == u of chunk c + 1 -> LDS, of chunk c + 2 -> registers
-  auto stage = [&](int c, int u, int gidx) {
+  // staging work of unit g = (chunk c, slice U; U < 0: a one-tap unit, every item): weights of unit g + 1 -> LDS,
+  // weights of unit g + 2 -> registers; halo items j % 3 == U of chunk c + 1 -> LDS, of chunk c + 2 -> registers.
+  // U is a compile-time constant: the item list of a unit is static and its stores / transforms / fetches sit in
+  // straight-line code (only block-uniform scalar branches around whole items).
+  auto stage = [&](int c, auto u_tag, int gidx) {
+    constexpr int U = decltype(u_tag)::value;
     PPROF_T(ts0);
     if (gidx + 1 < G) commit_b(gidx + 1);
     if (gidx + 2 < G) issue_b(gidx + 2);
     if (c + 1 < ntot) {
 #pragma unroll
       for (int j = 0; j < MAXIT; ++j)
-        if (u < 0 || (j % 3) == u) commit_a(c + 1, j);
+        if ((U < 0 || (j % 3) == U) && j < nitems) commit_a(c + 1, j);
     }
     if (c + 2 < ntot) {
 #pragma unroll
       for (int j = 0; j < MAXIT; ++j)
-        if (u < 0 || (j % 3) == u) issue_a(c + 2, j);
+        if ((U < 0 || (j % 3) == U) && j < nitems) issue_a(c + 2, j);
     }
     PPROF_T(ts1);
     PPROF_ADD(grp * 4 + 1, ts0, ts1);
   };
+  using U0 = std::integral_constant<int, 0>;
+  using U1 = std::integral_constant<int, 1>;
+  using U2 = std::integral_constant<int, 2>;
+  using UA = std::integral_constant<int, -1>;
 
   int gidx = 0;
+  auto unit = [&](int c, auto u_tag) {
+    constexpr int U = decltype(u_tag)::value;
+    const char* sAc = smemp + (c & 1) * abytes;
+    const char* sBu = sB + (gidx & 1) * UB;
+    if (grp == 0) stage(c, u_tag, gidx);
+    PPROF_T(tm0);
+    const char* sArow = sAc + U * WR * HRW;
+    tap(sArow, sBu, K0{});
+    tap(sArow, sBu + TAPB, K1{});
+    tap(sArow, sBu + 2 * TAPB, K2{});
+#ifdef RGFM_HX2P_PROF
+    asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[1][NT - 1][15]));
+#endif
+    PPROF_T(tm1);
+    if (grp != 0) stage(c, u_tag, gidx);
+    PPROF_T(tm2);
+    if (gidx != G - 1) __syncthreads();
+    PPROF_T(tm3);
+    PPROF_ADD(grp * 4 + 2, tm0, tm1);
+    PPROF_ADD(grp * 4 + 3, tm2, tm3);
+    ++gidx;
+  };
 #pragma unroll 1
   for (int c = 0; c < nmain; ++c) {
-    const char* sAc = smemp + (c & 1) * abytes;
-#pragma unroll 1
-    for (int u = 0; u < 3; ++u, ++gidx) {
-      const char* sBu = sB + (gidx & 1) * UB;
-      if (grp == 0) stage(c, u, gidx);
-      PPROF_T(tm0);
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) tap(sAc, sBu, u * WR + kx, kx * TAPB);
-#ifdef RGFM_HX2P_PROF
-      asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[1][NT - 1][15]));
-#endif
-      PPROF_T(tm1);
-      if (grp != 0) stage(c, u, gidx);
-      PPROF_T(tm2);
-      if (gidx != G - 1) __syncthreads();
-      PPROF_T(tm3);
-      PPROF_ADD(grp * 4 + 2, tm0, tm1);
-      PPROF_ADD(grp * 4 + 3, tm2, tm3);
-    }
+    unit(c, U0{});
+    unit(c, U1{});
+    unit(c, U2{});
   }
   if (nskip) {  // the 1x1 skip weights carry their own scale: q_main -> q_skip
     const float rs = a.hq_skip[0] * a.hq[1];
@@ -442,9 +475,9 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc[mt][nt] * rs;
 #pragma unroll 1
     for (int c = nmain; c < ntot; ++c, ++gidx) {
-      if (grp == 0) stage(c, -1, gidx);
-      tap(smemp + (c & 1) * abytes, sB + (gidx & 1) * UB, WR + 1, 0);
-      if (grp != 0) stage(c, -1, gidx);
+      if (grp == 0) stage(c, UA{}, gidx);
+      tap(smemp + (c & 1) * abytes + WR * HRW, sB + (gidx & 1) * UB, K1{});  // (centre tap: row 1, column 1)
+      if (grp != 0) stage(c, UA{}, gidx);
       if (gidx != G - 1) __syncthreads();
     }
   }
@@ -455,7 +488,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc[mt][nt] * qinv;
-    if (!(amax < HX_LIMIT)) atomicOr(a.range_flag, 1u);  // (rare) an activation left the fp16 range: the host re-runs on bx3
+    if (hmax[0] >= 0x7800 || hmax[1] >= 0x7800) atomicOr(a.range_flag, 1u);  // (rare) |a'| >= 32768 (or inf / nan): the host re-runs on bx3
   }
 
   // ---------------------------------------------------------------- epilogue (as conv_mfma_pf_kernel)
@@ -549,8 +582,8 @@ static size_t hx2p_lds_bytes(const ConvArgs& a) {
   const int nt = (a.Cout % 64 == 0) ? 2 : 1;
   const bool pn = hx2p_pairn(a);
   const int na = pn ? 1 : 2, nbt = 32 * nt * (pn ? 2 : 1);
-  size_t bytes = (size_t)2 * na * hx2p_halo(a) * HRW + (size_t)2 * 3 * nbt * HRW;  // two halo buffers + two weight units
-  if (a.gn_stats0) bytes += (size_t)na * a.g.spt * (a.C0 + a.C1) * 2 * sizeof(float);  // scale/shift table
+  size_t bytes = (size_t)2 * (na * hx2p_halo(a) + 1) * HRW + (size_t)2 * 3 * nbt * HRW;  // two halo buffers (+ pad record) + two weight units
+  if (a.gn_stats0) bytes += (size_t)(na * a.g.spt + 1) * (a.C0 + a.C1) * 2 * sizeof(float);  // scale/shift table + the zero row
   return bytes;
 }
 
