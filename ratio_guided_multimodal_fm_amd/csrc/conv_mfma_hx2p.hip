@@ -29,27 +29,44 @@
 
 namespace rgfm {
 
+#ifndef RGFM_HX2P_ABL
+#define RGFM_HX2P_ABL 0
+#endif
+#ifndef RGFM_HX2P_PRIO
+#define RGFM_HX2P_PRIO 0
+#endif
 #ifdef RGFM_HX2P_PROF
-// wave 0 / wave 4: [0]/[4] prologue + fill, [1]/[5] staging, [2]/[6] MFMA units, [3]/[7] barrier waits; [8] epilogue (wave 0); [9] blocks
-__device__ unsigned long long g_hx2p_prof[10];
+__device__ unsigned long long g_hx2p_prof[34];  // [wave][pro+fill, stage, mfma, barrier], [32] epilogue of wave 0, [33] blocks
 #define PPROF_T(var) const long long var = clock64()
 #define PPROF_ADD(slot, t0, t1) pacc[slot] += (t1) - (t0)
+__device__ long long g_hx2p_trace[2][64][9];  // block 3, waves 0 and 4: per unit {stage begin, stage end, mfma begin, mfma end, barrier begin, barrier end}
 #else
 #define PPROF_T(var)
 #define PPROF_ADD(slot, t0, t1)
 #endif
 
-template <int NT, int MODE, bool PAIRN>
-__global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a, const int num_tiles) {
+// CFG: how a workgroup is cut.  HX2P_TWO_TILES: 8 waves = two 256-pixel tiles x one channel group (32 NT channels), the
+// weights are staged once for both tiles; HX2P_PAIRN: 8 waves = one tile x two channel groups (Cout % 128 == 0), the
+// halo is staged once for both groups; HX2P_FOUR_WAVES: 4 waves = one tile x one group, 256 threads and at most 80 KB
+// of LDS, so that TWO workgroups share a CU and one's prologue / epilogue (memory round trips, every CU at once)
+// could run under the other's K loop (an experiment for the short-K layers, built only with -DRGFM_HX2P_W4_VARIANT).
+enum { HX2P_TWO_TILES = 0, HX2P_PAIRN = 1, HX2P_FOUR_WAVES = 2 };
+
+template <int NT, int MODE, int CFG>
+__global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a, const int num_tiles) {
+  constexpr bool PAIRN = CFG == HX2P_PAIRN;
+  constexpr bool W4 = CFG == HX2P_FOUR_WAVES;
+  constexpr int NTHR = W4 ? 256 : 512;
+
   static_assert(MODE == CONV_S1 || MODE == CONV_UP2, "stride-2 / transposed convs run on conv_mfma_hx2_kernel");
   constexpr int NG = PAIRN ? 2 : 1;            // channel groups per block
-  constexpr int NA = PAIRN ? 1 : 2;            // pixel tiles per block
+  constexpr int NA = (PAIRN || W4) ? 1 : 2;    // pixel tiles per block
   constexpr int NBLK = 32 * NT;                // channels per group
   constexpr int NBT = NBLK * NG;               // channels per block
   constexpr int TAPB = NBT * HRW;              // bytes of one tap's weight slab
   constexpr int UB = 3 * TAPB;                 // weights of one unit (3 taps)
-  constexpr int NB = (UB / 16 + 511) / 512;    // 16-byte weight items per thread and unit
-  constexpr int MAXIT = (NA * 448 * 4 + 511) / 512;  // halo items (pixel, 4 channels) per thread and chunk
+  constexpr int NB = (UB / 16 + NTHR - 1) / NTHR;    // 16-byte weight items per thread and unit
+  constexpr int MAXIT = (NA * 448 * 4 + NTHR - 1) / NTHR;  // halo items (pixel, 4 channels) per thread and chunk
   extern __shared__ __attribute__((aligned(16))) char smemp[];
 #ifdef RGFM_HX2P_PROF
   long long pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -57,10 +74,15 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
   PPROF_T(tk0);
   const int abytes = (NA * a.halo_px + 1) * HRW;  // one halo buffer (+ a pad record: the store target of lanes past the halo)
   char* const sB = smemp + 2 * abytes;         // two unit-sized weight buffers
-  float* const sTab = reinterpret_cast<float*>(sB + 2 * UB);  // [NA * spt][cin][2] S_A x (scale, shift)
+  float* const sTab = reinterpret_cast<float*>(sB + 2 * UB);  // [NA * spt][cin][2] S_A x (scale, shift) + a zero row
+  // per 16-channel chunk: {source pointer of the chunk's first channel (lo, hi), channel stride of that source, -}
+  char* const sDesc = reinterpret_cast<char*>(sTab) + (a.gn_stats0 ? (size_t)(NA * a.g.spt + 1) * (a.C0 + a.C1) * 8 : 0);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int grp = wave >> 2, seg = wave & 3;
+  const int grp = W4 ? 0 : wave >> 2, seg = wave & 3;
+  // which half of the staggered pair a wave is (0: stages before its MFMAs, 1: after): its wave group, or -- four
+  // waves: the partner on the SIMD belongs to another workgroup -- the parity of the workgroup
+  const int role = W4 ? (int)(blockIdx.x & 1) : grp;
   const int l31p = lane & 31, hp_ = lane >> 5;
   const TileGeom g = a.g;
   const int W = g.W, H = g.H, HW = g.HW;
@@ -78,10 +100,10 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
     }
   };
   int tb0_[2], trow0_[2];
-  tile_origin(PAIRN ? (int)blockIdx.x : (int)blockIdx.x * 2, tb0_[0], trow0_[0]);
-  tile_origin(PAIRN ? (int)blockIdx.x : (int)blockIdx.x * 2 + 1, tb0_[1], trow0_[1]);
-  const int ga_w = PAIRN ? 0 : grp;
-  const int my_tile = PAIRN ? (int)blockIdx.x : (int)blockIdx.x * 2 + grp;
+  tile_origin(NA == 1 ? (int)blockIdx.x : (int)blockIdx.x * 2, tb0_[0], trow0_[0]);
+  tile_origin(NA == 1 ? (int)blockIdx.x : (int)blockIdx.x * 2 + 1, tb0_[1], trow0_[1]);
+  const int ga_w = NA == 1 ? 0 : grp;
+  const int my_tile = NA == 1 ? (int)blockIdx.x : (int)blockIdx.x * 2 + grp;
   const int my_cb = PAIRN ? (int)blockIdx.y * 2 + grp : (int)blockIdx.y;
   const int b0 = ga_w ? tb0_[1] : tb0_[0], row0 = ga_w ? trow0_[1] : trow0_[0];
   // exact n / d for 0 <= n < 2048 as (n * m) >> 16 with m = ceil(65536 / d): full-rate 24-bit multiplies
@@ -109,7 +131,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
       q = (p & 63) < HW ? (p & 63) : HW - 1;
     }
     const int r = (int)(__umul24((unsigned)q, mW) >> 16), x = q - r * W;
-    arec[mt] = (PAIRN ? 0 : grp) * a.halo_px + (s * HR + r) * WR + x;
+    arec[mt] = ga_w * a.halo_px + (s * HR + r) * WR + x;
     // byte offset of this lane's fragment of tap (ky = 0, kx) inside a halo buffer, plane h / l: in THIS kernel the
     // four 16-byte slots of a halo record are swizzled with its halo column, (x >> 2) & 3 -- 16 consecutive
     // columns still cover all 16 slot columns of the bank row, and the term no longer depends on the kernel row,
@@ -133,9 +155,14 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
   const bool sample_ok = bw < a.B;
   const size_t pix0 = (g.spt == 1) ? (size_t)b0 * HW + (size_t)row0 * W : (size_t)bw * HW;
   const float qmain = a.hq[0];
+  PPROF_T(tkx);
   f32x16 acc[2][NT];
+  // bias (+ skip bias + time embedding) and, for an identity residual, the RAW residual values go into the
+  // accumulators here; they are scaled by q only after the pipeline fill (finish_acc below), so that the 64 residual
+  // loads of a lane are in flight during the item decode, the GroupNorm table and the fill instead of being waited
+  // for right here
+  float add0[NT];
   {
-    float add0[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int c = n0 + nt * 32 + l31p;
@@ -144,6 +171,10 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
       if (a.temb && sample_ok) v += a.temb[((size_t)(a.temb_per_row ? bw : 0) + (a.step_ptr ? (size_t)*a.step_ptr : 0)) * a.temb_stride + c];
       add0[nt] = v * qmain;  // the accumulators hold q x the true sums
     }
+    PPROF_T(tky);
+#ifdef RGFM_HX2P_PROF
+    if (blockIdx.x == 3 && seg == 0 && lane == 0) g_hx2p_trace[grp][63][5] = tkx - tk0, g_hx2p_trace[grp][63][6] = tky - tkx;
+#endif
     if (a.res_mode == 1) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
@@ -157,6 +188,10 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] = rp[nt * 32];
         }
+    }
+  }
+  auto finish_acc = [&]() {
+    if (a.res_mode == 1) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -171,8 +206,9 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[mt][nt][r] = add0[nt];
     }
-  }
+  };
 
+  PPROF_T(tka);
   // ---- per-item decode, once: source pixel offset, LDS destination, validity bit, scale/shift slot
   const int q4 = tid & 3;
   const int nA = a.halo_px * 4;
@@ -186,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
     const int per = HR * WR;
 #pragma unroll
     for (int j = 0; j < MAXIT; ++j) {
-      const int it = tid + 512 * j;
+      const int it = tid + NTHR * j;
       poff[j] = 0, adst[j] = NA * a.halo_px * HRW + (q4 >> 1) * 16 + (q4 & 1) * 8, trow[j] = (nrows_tab * (a.C0 + a.C1) + 4 * q4) * 8;
       if (it < NA * nA) {
         const int ga = (NA == 2 && it >= nA) ? 1 : 0;
@@ -237,31 +273,25 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
   // range flag: the largest |fp16| (as a bit pattern, per 16-bit half) this thread has stored; >= 0x7800 is |a'| >= 32768
   typedef unsigned short hx_u16x2 __attribute__((ext_vector_type(2)));
   hx_u16x2 hmax = {0, 0};
-  const int nitems = (NA * nA + 511) >> 9;  // items that exist for at least one thread (block-uniform)
+  const int nitems = (NA * nA + NTHR - 1) / NTHR;  // items that exist for at least one thread (block-uniform)
 
-  // raw fp32 fetch of item j of chunk ch
-  auto issue_a = [&](int ch, int j) {
-    const bool skip = ch >= nmain;
-    const float* src;
-    int cs, cc;
-    const int c = (skip ? ch - nmain : ch) * KC;
-    if (!skip) {
-      if (c < a.C0) src = a.in0, cs = a.C0, cc = c;
-      else src = a.in1, cs = a.C1, cc = c - a.C0;
-    } else {
-      if (c < a.R0) src = a.res0, cs = a.R0, cc = c;
-      else src = a.res1, cs = a.R1, cc = c - a.R0;
-    }
-    ra[j] = *(const hx_gf32x4*)(src + (size_t)(__umul24((unsigned)poff[j], (unsigned)cs) + (unsigned)(cc + q4 * 4)));
+  // raw fp32 fetch of item j of a chunk whose descriptor is d (chunk_desc)
+  typedef unsigned hx_u32x4 __attribute__((ext_vector_type(4)));
+  auto chunk_desc = [&](int ch) { return *reinterpret_cast<const hx_u32x4*>(sDesc + ch * 16); };
+  auto issue_a = [&](const hx_u32x4& d, int j) {
+    const float* src = reinterpret_cast<const float*>(((unsigned long long)d.y << 32) | (unsigned long long)d.x);
+    ra[j] = *(const hx_gf32x4*)(src + (size_t)(__umul24((unsigned)poff[j], d.z) + (unsigned)(q4 * 4)));
+  };
+  // scale/shift pairs of item j's four channels in chunk ch (read ahead of the stores of a staging phase)
+  auto table_a = [&](int ch, int j, f32x4& e0, f32x4& e1) {
+    const char* ep = reinterpret_cast<const char*>(sTab) + ch * (KC * 8) + trow[j];
+    e0 = *reinterpret_cast<const f32x4*>(ep);
+    e1 = *reinterpret_cast<const f32x4*>(ep + 16);
   };
   // GroupNorm + SiLU + split + store of item j of chunk ch into halo buffer ch & 1 (branch-free per lane)
-  auto commit_a = [&](int ch, int j) {
-    const bool xform = ch < nmain && a.gn_stats0 != nullptr;
+  auto commit_a = [&](int ch, int j, bool xform, const f32x4& e0, const f32x4& e1) {
     f32x4 v = ra[j];
     if (xform) {
-      const char* ep = reinterpret_cast<const char*>(sTab) + ch * (KC * 8) + trow[j];
-      const f32x4 e0 = *reinterpret_cast<const f32x4*>(ep);
-      const f32x4 e1 = *reinterpret_cast<const f32x4*>(ep + 16);
       v.x = silu_scaled(fmaf(e0.x, v.x, e0.y));
       v.y = silu_scaled(fmaf(e0.z, v.y, e0.w));
       v.z = silu_scaled(fmaf(e1.x, v.z, e1.y));
@@ -288,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
     const int nit = main ? UB / 16 : TAPB / 16;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      const int it = tid + 512 * j;
+      const int it = tid + NTHR * j;
       rb[j] = *(const hx_gf32x4*)(src + (size_t)(it < nit ? it : 0) * 16);
     }
   };
@@ -297,11 +327,12 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
     char* dst = sB + (gg & 1) * UB;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      const int it = tid + 512 * j;
+      const int it = tid + NTHR * j;
       if (it < nit) *reinterpret_cast<f32x4*>(dst + it * 16) = rb[j];
     }
   };
 
+  PPROF_T(tkb);
   if (a.gn_stats0) {
     // ---- consumer-side GroupNorm: scale/shift of this block's sample(s) from the producers' partial statistics,
     // before chunk 0's prefetch registers come alive (with them the partials would spill).  Wave w owns table row
@@ -364,30 +395,77 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
   }
 
   if (a.gn_stats0)  // the all-zero row of the padding items
-    for (int i = tid; i < 2 * (a.C0 + a.C1); i += 512) sTab[nrows_tab * (a.C0 + a.C1) * 2 + i] = 0.f;
-  __syncthreads();  // the scale/shift table is complete
+    for (int i = tid; i < 2 * (a.C0 + a.C1); i += NTHR) sTab[nrows_tab * (a.C0 + a.C1) * 2 + i] = 0.f;
+  if (tid < ntot) {  // chunk descriptors: which tensor a chunk comes from (input / concat partner / 1x1-skip sources)
+    const bool skip = tid >= nmain;
+    const int c = (skip ? tid - nmain : tid) * KC;
+    const float* src;
+    int cs, cc;
+    if (!skip) {
+      if (c < a.C0) src = a.in0, cs = a.C0, cc = c;
+      else src = a.in1, cs = a.C1, cc = c - a.C0;
+    } else {
+      if (c < a.R0) src = a.res0, cs = a.R0, cc = c;
+      else src = a.res1, cs = a.R1, cc = c - a.R0;
+    }
+    const unsigned long long pv = reinterpret_cast<unsigned long long>(src + cc);
+    const hx_u32x4 d = {(unsigned)pv, (unsigned)(pv >> 32), (unsigned)cs, 0u};
+    *reinterpret_cast<hx_u32x4*>(sDesc + tid * 16) = d;
+  }
+  PPROF_T(tkc);
+  __syncthreads();  // the scale/shift table and the chunk descriptors are complete
+  PPROF_T(tkd);
+  const bool gn_on = a.gn_stats0 != nullptr;
   // ---- pipeline fill: halo of chunk 0 and weights of unit 0 in LDS, raw halo of chunk 1 and weights of unit 1 in registers
+  {
+    const hx_u32x4 d0 = chunk_desc(0);
 #pragma unroll
-  for (int j = 0; j < MAXIT; ++j)
-    if (j < nitems) issue_a(0, j);
-  issue_b(0);
+    for (int j = 0; j < MAXIT; ++j)
+      if (j < nitems) issue_a(d0, j);
+    issue_b(0);
 #pragma unroll
-  for (int j = 0; j < MAXIT; ++j)
-    if (j < nitems) commit_a(0, j);
-  commit_b(0);
+    for (int j = 0; j < MAXIT; ++j)
+      if (j < nitems) {
+        f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = e0;
+        const bool xf = gn_on && 0 < nmain;
+        if (xf) table_a(0, j, e0, e1);
+        commit_a(0, j, xf, e0, e1);
+      }
+    commit_b(0);
+    if (ntot > 1) {
+      const hx_u32x4 d1 = chunk_desc(1);
 #pragma unroll
-  for (int j = 0; j < MAXIT; ++j)
-    if (j < nitems) issue_a(1, j);
-  issue_b(1);
+      for (int j = 0; j < MAXIT; ++j)
+        if (j < nitems) issue_a(d1, j);
+    }
+    issue_b(1);
+  }
+  finish_acc();
   __syncthreads();
   PPROF_T(tk1);
   PPROF_ADD(grp * 4 + 0, tk0, tk1);
+#ifdef RGFM_HX2P_PROF
+  if (blockIdx.x == 3 && seg == 0 && lane == 0) {
+    long long* tr = g_hx2p_trace[grp][63];
+    tr[0] = tka - tk0, tr[1] = tkb - tka, tr[2] = tkc - tkb, tr[3] = tkd - tkc, tr[4] = tk1 - tkd;
+  }
+#endif
 
   // one tap (kernel column KX of the row at byte offset `rowoff`): fragments of this wave's 2 pixel tiles x NT channel
   // tiles, 3 MFMAs per tile pair
+#if RGFM_HX2P_ABL == 1  // (timing ablation: fragments read once, results wrong)
+  f16x8 af[2][2], bf[NT][2];
+  bool frag_once = false;
+#endif
   auto tap = [&](const char* sArow, const char* sBt, auto kx_tag) {
     constexpr int KX = decltype(kx_tag)::value;
+#if RGFM_HX2P_ABL == 1
+    if (!frag_once) {
+      frag_once = true;
+#else
     f16x8 af[2][2], bf[NT][2];
+    {
+#endif
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       af[mt][0] = *reinterpret_cast<const f16x8*>(sArow + aofs[mt][KX][0]);
@@ -397,6 +475,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
     for (int nt = 0; nt < NT; ++nt) {
       bf[nt][0] = *reinterpret_cast<const f16x8*>(sBt + bbase[nt]);
       bf[nt][1] = *reinterpret_cast<const f16x8*>(sBt + bsw[nt]);
+    }
     }
     constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};  // a_l w_h, a_h w_l, a_h w_h
 #pragma unroll
@@ -415,23 +494,66 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
   // weights of unit g + 2 -> registers; halo items j % 3 == U of chunk c + 1 -> LDS, of chunk c + 2 -> registers.
   // U is a compile-time constant: the item list of a unit is static and its stores / transforms / fetches sit in
   // straight-line code (only block-uniform scalar branches around whole items).
+#ifdef RGFM_HX2P_PROF
+  long long st_begin = 0, st_end = 0, st_a = 0, st_b = 0, st_c = 0;
+#endif
   auto stage = [&](int c, auto u_tag, int gidx) {
     constexpr int U = decltype(u_tag)::value;
     PPROF_T(ts0);
+    // Order: (1) LDS reads the phase needs (descriptor of chunk c + 2, scale/shift pairs of this unit's items) ahead of
+    // every store; (2) every consumer of a fetched register; (3) every new fetch, the halo's first.  hipcc cannot
+    // count loads across the loop's back edge and waits for vmcnt(0) before the first use (or re-use) of a register
+    // fetched in an earlier unit: with a fresh fetch already in flight that would be a full memory round trip
+    // inside every staging phase.
+    constexpr int NU = (U < 0) ? MAXIT : (MAXIT + 2 - U) / 3;  // items of this unit: j = U, U + 3, ... (all of them in a one-tap unit)
+    const bool have1 = c + 1 < ntot, have2 = c + 2 < ntot;
+    const bool xf = gn_on && c + 1 < nmain;
+    hx_u32x4 dn = {0u, 0u, 0u, 0u};
+    if (have2) dn = chunk_desc(c + 2);
+    f32x4 e0[NU], e1[NU];
+    if (have1 && xf) {
+#pragma unroll
+      for (int k = 0; k < NU; ++k) {
+        const int j = (U < 0) ? k : U + 3 * k;
+        if (j < nitems) table_a(c + 1, j, e0[k], e1[k]);
+      }
+    }
+#if RGFM_HX2P_ABL != 4
     if (gidx + 1 < G) commit_b(gidx + 1);
+#endif
+    PPROF_T(tsa);
+#if RGFM_HX2P_ABL == 6
+    if (false) {
+#else
+    if (have1) {
+#endif
+#pragma unroll
+      for (int k = 0; k < NU; ++k) {
+        const int j = (U < 0) ? k : U + 3 * k;
+        if (j < nitems) commit_a(c + 1, j, RGFM_HX2P_ABL == 3 ? false : xf, e0[k], e1[k]);
+      }
+    }
+    PPROF_T(tsb);
+#if RGFM_HX2P_ABL == 5
+    if (false) {
+#else
+    if (have2) {
+#endif
+#pragma unroll
+      for (int k = 0; k < NU; ++k) {
+        const int j = (U < 0) ? k : U + 3 * k;
+        if (j < nitems) issue_a(dn, j);
+      }
+    }
+    PPROF_T(tsc);
+#if RGFM_HX2P_ABL != 5
     if (gidx + 2 < G) issue_b(gidx + 2);
-    if (c + 1 < ntot) {
-#pragma unroll
-      for (int j = 0; j < MAXIT; ++j)
-        if ((U < 0 || (j % 3) == U) && j < nitems) commit_a(c + 1, j);
-    }
-    if (c + 2 < ntot) {
-#pragma unroll
-      for (int j = 0; j < MAXIT; ++j)
-        if ((U < 0 || (j % 3) == U) && j < nitems) issue_a(c + 2, j);
-    }
+#endif
     PPROF_T(ts1);
     PPROF_ADD(grp * 4 + 1, ts0, ts1);
+#ifdef RGFM_HX2P_PROF
+    st_begin = ts0, st_end = ts1, st_a = tsa, st_b = tsb, st_c = tsc;
+#endif
   };
   using U0 = std::integral_constant<int, 0>;
   using U1 = std::integral_constant<int, 1>;
@@ -443,22 +565,40 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
     constexpr int U = decltype(u_tag)::value;
     const char* sAc = smemp + (c & 1) * abytes;
     const char* sBu = sB + (gidx & 1) * UB;
-    if (grp == 0) stage(c, u_tag, gidx);
+#if RGFM_HX2P_ABL != 2  // (timing ablation 2: no staging in the loop, results wrong)
+    if (role == 0) stage(c, u_tag, gidx);
+#endif
     PPROF_T(tm0);
     const char* sArow = sAc + U * WR * HRW;
+#if RGFM_HX2P_PRIO
+    // waves 4-7 multiply first: their MFMAs go ahead of those of waves 0-3 (which arrive from their staging while
+    // this phase is still running), so that THEIR staging then runs beside the partner's remaining MFMAs
+    if (role != 0) __builtin_amdgcn_s_setprio(RGFM_HX2P_PRIO);
+#endif
     tap(sArow, sBu, K0{});
     tap(sArow, sBu + TAPB, K1{});
     tap(sArow, sBu + 2 * TAPB, K2{});
+#if RGFM_HX2P_PRIO
+    if (role != 0) __builtin_amdgcn_s_setprio(0);
+#endif
 #ifdef RGFM_HX2P_PROF
     asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[1][NT - 1][15]));
 #endif
     PPROF_T(tm1);
-    if (grp != 0) stage(c, u_tag, gidx);
+#if RGFM_HX2P_ABL != 2
+    if (role != 0) stage(c, u_tag, gidx);
+#endif
     PPROF_T(tm2);
     if (gidx != G - 1) __syncthreads();
     PPROF_T(tm3);
     PPROF_ADD(grp * 4 + 2, tm0, tm1);
     PPROF_ADD(grp * 4 + 3, tm2, tm3);
+#ifdef RGFM_HX2P_PROF
+    if (blockIdx.x == 3 && seg == 0 && lane == 0 && gidx < 63) {
+      long long* tr = g_hx2p_trace[grp][gidx];
+      tr[0] = st_begin, tr[1] = st_end, tr[2] = tm0, tr[3] = tm1, tr[4] = tm2, tr[5] = tm3, tr[6] = st_a, tr[7] = st_b, tr[8] = st_c;
+    }
+#endif
     ++gidx;
   };
 #pragma unroll 1
@@ -475,9 +615,9 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc[mt][nt] * rs;
 #pragma unroll 1
     for (int c = nmain; c < ntot; ++c, ++gidx) {
-      if (grp == 0) stage(c, UA{}, gidx);
+      if (role == 0) stage(c, UA{}, gidx);
       tap(smemp + (c & 1) * abytes + WR * HRW, sB + (gidx & 1) * UB, K1{});  // (centre tap: row 1, column 1)
-      if (grp != 0) stage(c, UA{}, gidx);
+      if (role != 0) stage(c, UA{}, gidx);
       if (gidx != G - 1) __syncthreads();
     }
   }
@@ -515,7 +655,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
           pix = (unsigned)((bw * (2 * H) + 2 * rr + py) * (2 * W) + 2 * xx + px);
         }
         float* op = a.out + (size_t)(__umul24(pix, (unsigned)a.Cout) + (unsigned)(n0 + l31));
-        if (valid) {
+        if (valid && (RGFM_HX2P_ABL != 7 || acc[mt][0][r] == 1.2345f)) {  // (ablation 7: no output stores)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) op[nt * 32] = acc[mt][nt][r];
         }
@@ -568,23 +708,36 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a
 #ifdef RGFM_HX2P_PROF
   PPROF_T(te1);
   PPROF_ADD(8, te0, te1);
-  if ((tid & 255) == 0) {
-    for (int i = grp * 4; i < grp * 4 + 4; ++i) atomicAdd(&g_hx2p_prof[i], (unsigned long long)pacc[i]);
-    if (tid == 0) atomicAdd(&g_hx2p_prof[8], (unsigned long long)pacc[8]), atomicAdd(&g_hx2p_prof[9], 1ull);
+  if (lane == 0) {
+    for (int i = 0; i < 4; ++i) atomicAdd(&g_hx2p_prof[wave * 4 + i], (unsigned long long)pacc[grp * 4 + i]);
+    if (tid == 0) atomicAdd(&g_hx2p_prof[32], (unsigned long long)pacc[8]), atomicAdd(&g_hx2p_prof[33], 1ull);
   }
 #endif
 }
 
 // ---------------------------------------------------------------- host side
 static int hx2p_halo(const ConvArgs& a) { return a.g.spt * (a.g.th + 2) * (a.g.W + 2); }
-static bool hx2p_pairn(const ConvArgs& a) { return a.Cout % 128 == 0; }
-static size_t hx2p_lds_bytes(const ConvArgs& a) {
+static size_t hx2p_lds_bytes(const ConvArgs& a, int cfg) {
   const int nt = (a.Cout % 64 == 0) ? 2 : 1;
-  const bool pn = hx2p_pairn(a);
-  const int na = pn ? 1 : 2, nbt = 32 * nt * (pn ? 2 : 1);
+  const int na = cfg == HX2P_TWO_TILES ? 2 : 1, nbt = 32 * nt * (cfg == HX2P_PAIRN ? 2 : 1);
   size_t bytes = (size_t)2 * (na * hx2p_halo(a) + 1) * HRW + (size_t)2 * 3 * nbt * HRW;  // two halo buffers (+ pad record) + two weight units
   if (a.gn_stats0) bytes += (size_t)(na * a.g.spt + 1) * (a.C0 + a.C1) * 2 * sizeof(float);  // scale/shift table + the zero row
+  bytes += (size_t)(a.C0 + a.C1 + (a.res_mode == 2 ? a.R0 + a.R1 : 0));                    // 16 bytes per 16-channel chunk: descriptors
   return bytes;
+}
+// The four-wave configuration is a measured dead end on this workload (a four-wave workgroup takes as long
+// as an eight-wave one, co-resident or not; whole bench 438 vs 450 paired images/s with it on the Cin <= 32 layers),
+// so the library does not instantiate it; tools/kbench builds it with -DRGFM_HX2P_W4_VARIANT and selects it with
+// RGFM_HX2P_W4 = 1 (layers with Cout % 128 != 0) or 2 (every layer whose LDS need allows two workgroups per CU).
+static int g_hx2p_w4 = 0;
+void conv_hx2p_set_w4(int v) { g_hx2p_w4 = v; }
+static int hx2p_cfg(const ConvArgs& a) {
+#ifdef RGFM_HX2P_W4_VARIANT
+  const bool fits = hx2p_lds_bytes(a, HX2P_FOUR_WAVES) <= 80 * 1024;  // two workgroups per CU
+  if (g_hx2p_w4 == 2 && fits) return HX2P_FOUR_WAVES;
+  if (g_hx2p_w4 == 1 && fits && a.Cout % 128 != 0) return HX2P_FOUR_WAVES;
+#endif
+  return (a.Cout % 128 == 0) ? HX2P_PAIRN : HX2P_TWO_TILES;
 }
 
 // the pipelined kernel takes: stride-1 / upsampling convs whose input norm (if any) is the consumer-side one
@@ -593,16 +746,20 @@ bool conv_hx2p_supported(const ConvArgs& a, int mode) {
   if (a.ab && !a.gn_stats0) return false;
   if (!conv_hx2_supported(a, mode)) return false;
   if (a.gn_stats0 && !conv_hx2_gn_supported(a, mode)) return false;
-  return hx2p_halo(a) <= 448 && hx2p_lds_bytes(a) <= 160 * 1024;
+  return hx2p_halo(a) <= 448 && hx2p_lds_bytes(a, hx2p_cfg(a)) <= 160 * 1024;
 }
 
 int conv_hx2p_init() {
   int rc = 0;
 #define RAISEP(NTV, M, P) rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_hx2p_kernel<NTV, M, P>), \
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-  RAISEP(1, CONV_S1, false); RAISEP(1, CONV_UP2, false);
-  RAISEP(2, CONV_S1, false); RAISEP(2, CONV_UP2, false);
-  RAISEP(2, CONV_S1, true); RAISEP(2, CONV_UP2, true);
+  RAISEP(1, CONV_S1, HX2P_TWO_TILES); RAISEP(1, CONV_UP2, HX2P_TWO_TILES);
+  RAISEP(2, CONV_S1, HX2P_TWO_TILES); RAISEP(2, CONV_UP2, HX2P_TWO_TILES);
+  RAISEP(2, CONV_S1, HX2P_PAIRN); RAISEP(2, CONV_UP2, HX2P_PAIRN);
+#ifdef RGFM_HX2P_W4_VARIANT
+  RAISEP(1, CONV_S1, HX2P_FOUR_WAVES); RAISEP(1, CONV_UP2, HX2P_FOUR_WAVES);
+  RAISEP(2, CONV_S1, HX2P_FOUR_WAVES); RAISEP(2, CONV_UP2, HX2P_FOUR_WAVES);
+#endif
 #undef RAISEP
   return rc;
 }
@@ -612,20 +769,27 @@ void launch_conv_hx2p(const ConvArgs& a_in, int mode, hipStream_t s) {
   a.halo_px = hx2p_halo(a_in);
   const int nt = (a.Cout % 64 == 0) ? 2 : 1;
   const int tiles = geom_num_tiles(a.g, a.B);
-  const bool pn = hx2p_pairn(a);
-  dim3 grid(pn ? tiles : (tiles + 1) / 2, pn ? a.Cout / 128 : a.Cout / (32 * nt), 1);
-  const size_t lds = hx2p_lds_bytes(a);
-#define LAUNCHP(NTV, M, P) hipLaunchKernelGGL((conv_mfma_hx2p_kernel<NTV, M, P>), grid, dim3(512), lds, s, a, tiles)
-  if (pn) {
-    if (mode == CONV_S1) LAUNCHP(2, CONV_S1, true);
-    else LAUNCHP(2, CONV_UP2, true);
-  } else if (nt == 2) {
-    if (mode == CONV_S1) LAUNCHP(2, CONV_S1, false);
-    else LAUNCHP(2, CONV_UP2, false);
-  } else {
-    if (mode == CONV_S1) LAUNCHP(1, CONV_S1, false);
-    else LAUNCHP(1, CONV_UP2, false);
+  const int cfg = hx2p_cfg(a);
+  dim3 grid(cfg == HX2P_TWO_TILES ? (tiles + 1) / 2 : tiles, cfg == HX2P_PAIRN ? a.Cout / 128 : a.Cout / (32 * nt), 1);
+  const size_t lds = hx2p_lds_bytes(a, cfg);
+#define LAUNCHP(NTV, M, P) hipLaunchKernelGGL((conv_mfma_hx2p_kernel<NTV, M, P>), grid, dim3(P == HX2P_FOUR_WAVES ? 256 : 512), lds, s, a, tiles)
+#define LAUNCHM(NTV, P)                           \
+  do {                                            \
+    if (mode == CONV_S1) LAUNCHP(NTV, CONV_S1, P); \
+    else LAUNCHP(NTV, CONV_UP2, P);               \
+  } while (0)
+  if (cfg == HX2P_PAIRN) LAUNCHM(2, HX2P_PAIRN);
+#ifdef RGFM_HX2P_W4_VARIANT
+  else if (cfg == HX2P_FOUR_WAVES) {
+    if (nt == 2) LAUNCHM(2, HX2P_FOUR_WAVES);
+    else LAUNCHM(1, HX2P_FOUR_WAVES);
   }
+#endif
+  else {
+    if (nt == 2) LAUNCHM(2, HX2P_TWO_TILES);
+    else LAUNCHM(1, HX2P_TWO_TILES);
+  }
+#undef LAUNCHM
 #undef LAUNCHP
 }
 

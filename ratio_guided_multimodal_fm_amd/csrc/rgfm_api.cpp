@@ -228,7 +228,8 @@ bool on_gfx950() {
 //               | f32 (conv_mfma.hip: v_mfma_f32_32x32x2_f32 everywhere);
 //   RGFM_OVERLAP=0   both velocity nets of a step on the caller's stream;
 //   RGFM_FUSE_FIN=0  separate gn_finalize launches instead of the producer-side finalize;
-//   RGFM_GN=table    every GroupNorm finalized into a scale/shift array instead of the consumer-side prologue.
+//   RGFM_GN=table    every GroupNorm finalized into a scale/shift array instead of the consumer-side prologue;
+//   RGFM_HX2P=0, RGFM_GRAPH=1: A/B switches of the pipelined fp16 kernel and the hipGraph replay.
 enum { CONV_ARITH_HX2 = 0, CONV_ARITH_BX3 = 1, CONV_ARITH_F32 = 2 };
 struct Modes {
   int conv = CONV_ARITH_HX2;

@@ -82,6 +82,8 @@ __device__ __forceinline__ void fin_sample(const ConvArgs& a, int b, int lane, i
 // agent-scope atomic store that goes to the coherence point.
 __device__ __forceinline__ void store_stats(const ConvArgs& a, float* sp, float mean, float m2) {
   if (a.fin_ab) {
+    static_assert(sizeof(unsigned long long) == 2 * sizeof(float), "(mean, M2) pair is published as one 8-byte store");
+    // slots are float2-indexed from a 256-byte-aligned workspace region (host: Bump::f), so sp is 8-byte aligned
     const unsigned long long bits = (unsigned long long)__float_as_uint(mean) | ((unsigned long long)__float_as_uint(m2) << 32);
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(sp), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
@@ -102,6 +104,8 @@ __device__ __forceinline__ void fin_arrive(const ConvArgs& a, int b, int lane, i
     last = (__hip_atomic_fetch_add(a.fin_counter + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
             (unsigned)(a.fin_expected - 1)) ? 1u : 0u;
   last = __shfl(last, 0);
+  // the statistics loads of fin_sample must not be hoisted above the counter's result by the compiler
+  asm volatile("" ::: "memory");
   if (last) {
     fin_sample(a, b, lane, nparts0, t2);
     if (lane == 0) __hip_atomic_store(a.fin_counter + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -62,6 +62,8 @@ int main(int argc, char** argv) {
   conv_bx3_init();
   conv_hx2_init();
   conv_hx2p_init();
+  if (getenv("RGFM_HX2P_W4")) conv_hx2p_set_w4(atoi(getenv("RGFM_HX2P_W4")));
+
   ConvArgs a{};
   a.in0 = dev_rand((size_t)B * Sin * Sin * Cin, 1.f, 1);
   a.C0 = Cin, a.Hin = a.Win = Sin;
@@ -180,7 +182,7 @@ int main(int argc, char** argv) {
     printf("check vs f32 kernel: max|diff| %.3e (max|ref| %.3f), stats rel diff %.3e, range flag %u\n", emax, vmax, smax, fl);
   }
 #ifdef RGFM_HX2P_PROF
-  unsigned long long zerop[10] = {0};
+  unsigned long long zerop[34] = {0};
   hipMemcpyToSymbol(HIP_SYMBOL(g_hx2p_prof), zerop, sizeof(zerop));
 #endif
 #if defined(RGFM_BX3_PROF) || defined(RGFM_HX2_PROF)
@@ -205,11 +207,29 @@ int main(int argc, char** argv) {
          Cout, mode, res, B, us, flops / us / 1e6);
 #ifdef RGFM_HX2P_PROF
   {
-    unsigned long long pp[10];
+    unsigned long long pp[34];
     hipMemcpyFromSymbol(pp, HIP_SYMBOL(g_hx2p_prof), sizeof(pp));
-    const double nbk = (double)pp[9];
-    const char* nm[9] = {"w0:pro+fill", "w0:stage", "w0:mfma", "w0:barrier", "w4:pro+fill", "w4:stage", "w4:mfma", "w4:barrier", "w0:epilogue"};
-    for (int i = 0; i < 9; ++i) printf("  %-12s %10.0f clk/block\n", nm[i], pp[i] / nbk);
+    const double nbk = (double)pp[33];
+    printf("  wave   pro+fill    stage     mfma  barrier  (clk/block)\n");
+    for (int w = 0; w < 8; ++w)
+      printf("  w%d   %9.0f %8.0f %8.0f %8.0f\n", w, pp[w * 4] / nbk, pp[w * 4 + 1] / nbk, pp[w * 4 + 2] / nbk, pp[w * 4 + 3] / nbk);
+    printf("  w0 epilogue %.0f\n", pp[32] / nbk);
+    static long long tr[2][64][9];
+    hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_hx2p_trace), sizeof(tr));
+    const long long t0 = tr[1][4][2];
+    printf("  trace of block 3 (cycles since unit 4's start): unit | w0: stage[b,e] mfma[b,e] barrier[b,e] | w4: mfma[b,e] stage[b,e] barrier[b,e]\n");
+    for (int u = 4; u < 14; ++u)
+      printf("  u%02d | %6lld %6lld  %6lld %6lld  %6lld %6lld | %6lld %6lld  %6lld %6lld  %6lld %6lld\n", u, tr[0][u][0] - t0, tr[0][u][1] - t0,
+             tr[0][u][2] - t0, tr[0][u][3] - t0, tr[0][u][4] - t0, tr[0][u][5] - t0, tr[1][u][2] - t0, tr[1][u][3] - t0, tr[1][u][0] - t0,
+             tr[1][u][1] - t0, tr[1][u][4] - t0, tr[1][u][5] - t0);
+    printf("  prologue of block 3 (index + acc init | item decode | GN table | barrier | fill): w0 %lld %lld %lld %lld %lld | w4 %lld %lld %lld %lld %lld\n",
+           tr[0][63][0], tr[0][63][1], tr[0][63][2], tr[0][63][3], tr[0][63][4], tr[1][63][0], tr[1][63][1], tr[1][63][2], tr[1][63][3], tr[1][63][4]);
+    printf("  acc-init section: index math w0 %lld w4 %lld | bias/temb w0 %lld w4 %lld\n", tr[0][63][5], tr[1][63][5], tr[0][63][6], tr[1][63][6]);
+    printf("  stage split (commit_b | commit_a | issue_b | issue_a):\n");
+    for (int u = 4; u < 14; ++u)
+      printf("  u%02d | w0 %5lld %5lld %5lld %5lld | w4 %5lld %5lld %5lld %5lld\n", u, tr[0][u][6] - tr[0][u][0], tr[0][u][7] - tr[0][u][6],
+             tr[0][u][8] - tr[0][u][7], tr[0][u][1] - tr[0][u][8], tr[1][u][6] - tr[1][u][0], tr[1][u][7] - tr[1][u][6],
+             tr[1][u][8] - tr[1][u][7], tr[1][u][1] - tr[1][u][8]);
   }
 #endif
 #if defined(RGFM_BX3_PROF) || defined(RGFM_HX2_PROF)
