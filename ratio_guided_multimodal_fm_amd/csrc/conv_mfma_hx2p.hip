@@ -32,6 +32,9 @@ namespace rgfm {
 #ifndef RGFM_HX2P_ABL
 #define RGFM_HX2P_ABL 0
 #endif
+#ifndef RGFM_HX2P_FAST
+#define RGFM_HX2P_FAST 1
+#endif
 #ifndef RGFM_HX2P_PRIO
 #define RGFM_HX2P_PRIO 0
 #endif
@@ -270,6 +273,14 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
   const char* wsk = reinterpret_cast<const char*>(a.wskiph) + (size_t)blockIdx.y * nskip * TAPB;
 
   f32x4 ra[MAXIT], rb[NB];
+  // byte offset of this thread's j-th 16-byte weight item of a 3-tap unit; threads past the unit's last item repeat an
+  // earlier one (same bytes to the same address), so the fast path below copies without per-lane predicates
+  int boff[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int it = tid + NTHR * j;
+    boff[j] = (it < UB / 16 ? it : it - UB / 16) * 16;
+  }
   // range flag: the largest |fp16| (as a bit pattern, per 16-bit half) this thread has stored; >= 0x7800 is |a'| >= 32768
   typedef unsigned short hx_u16x2 __attribute__((ext_vector_type(2)));
   hx_u16x2 hmax = {0, 0};
@@ -319,7 +330,7 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int it = tid + NTHR * j;
-      rb[j] = *(const hx_gf32x4*)(src + (size_t)(it < nit ? it : 0) * 16);
+      rb[j] = *(const hx_gf32x4*)(src + (main ? boff[j] : (it < nit ? it : 0) * 16));  // (main: as the fast unit fetches)
     }
   };
   auto commit_b = [&](int gg) {
@@ -561,6 +572,82 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
   using UA = std::integral_constant<int, -1>;
 
   int gidx = 0;
+  // ---- FAST unit (chunks 0 .. nmain - 2 of a conv whose input takes the consumer-side GroupNorm): one straight-line
+  // instruction stream per unit in which the staging work sits BETWEEN the three taps' MFMAs instead of in a phase of
+  // its own.  A wave's unit time is then max(MFMA time, issue time of everything else) rather than their sum: the
+  // vmcnt wait, the table read and the exp / rcp chains of the transform complete under MFMAs that are already in
+  // the pipe.  LDS operations keep the order written here (hipcc cannot tell the buffers apart), vector ALU and
+  // global loads may move across the segment marks (sched_barrier mask), MFMAs and LDS operations may not.
+  //   consumers of fetched registers (weights -> LDS, halo item -> transform -> LDS) come first and the new fetches
+  //   right behind them, at ONE point of the unit: every fetch is a full unit old when hipcc's vmcnt(0) meets it.
+  auto frag = [&](const char* sArow, const char* sBt, auto kx_tag, f16x8 (&af)[2][2], f16x8 (&bf)[NT][2]) {
+    constexpr int KX = decltype(kx_tag)::value;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      af[mt][0] = *reinterpret_cast<const f16x8*>(sArow + aofs[mt][KX][0]);
+      af[mt][1] = *reinterpret_cast<const f16x8*>(sArow + aofs[mt][KX][1]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      bf[nt][0] = *reinterpret_cast<const f16x8*>(sBt + bbase[nt]);
+      bf[nt][1] = *reinterpret_cast<const f16x8*>(sBt + bsw[nt]);
+    }
+  };
+  auto mfma_tap = [&](const f16x8 (&af)[2][2], const f16x8 (&bf)[NT][2]) {
+    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};  // a_l w_h, a_h w_l, a_h w_h
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt][PA[q]], bf[nt][PB[q]], acc[mt][nt], 0, 0, 0);
+  };
+#define HX2P_SEG() __builtin_amdgcn_sched_barrier(0x0002 | 0x0004 | 0x0010 | 0x0400)  // VALU, SALU, VMEM, transcendentals may cross
+  auto unit_fast = [&](int c, auto u_tag) {
+    constexpr int U = decltype(u_tag)::value;
+    constexpr int NU = (MAXIT + 2 - U) / 3;
+    const char* sArow = smemp + (c & 1) * abytes + U * WR * HRW;
+    const char* sBu = sB + (gidx & 1) * UB;
+    char* sBn = sB + ((gidx + 1) & 1) * UB;
+    const char* wsrc = wpk + (size_t)(gidx + 2) * UB;
+    f16x8 af0[2][2], bf0[NT][2], af1[2][2], bf1[NT][2];
+    frag(sArow, sBu, K0{}, af0, bf0);
+    const int c2 = c + 2 < ntot ? c + 2 : ntot - 1;  // (no such chunk: a harmless re-fetch, never committed)
+    const hx_u32x4 dn = chunk_desc(c2);
+    f32x4 e0[NU], e1[NU];
+    table_a(c + 1, U, e0[0], e1[0]);
+    HX2P_SEG();
+    frag(sArow, sBu + TAPB, K1{}, af1, bf1);
+    mfma_tap(af0, bf0);
+    HX2P_SEG();
+#if RGFM_HX2P_ABL != 4 && RGFM_HX2P_ABL != 2
+#pragma unroll
+    for (int j = 0; j < NB; ++j) *reinterpret_cast<f32x4*>(sBn + boff[j]) = rb[j];
+#endif
+#if RGFM_HX2P_ABL != 6 && RGFM_HX2P_ABL != 2
+    commit_a(c + 1, U, RGFM_HX2P_ABL != 3, e0[0], e1[0]);
+#pragma unroll
+    for (int k = 1; k < NU; ++k)
+      if (U + 3 * k < nitems) {
+        table_a(c + 1, U + 3 * k, e0[k], e1[k]);
+        commit_a(c + 1, U + 3 * k, RGFM_HX2P_ABL != 3, e0[k], e1[k]);
+      }
+#endif
+#if RGFM_HX2P_ABL != 5 && RGFM_HX2P_ABL != 2
+#pragma unroll
+    for (int k = 0; k < NU; ++k)
+      if (k == 0 || U + 3 * k < nitems) issue_a(dn, U + 3 * k);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) rb[j] = *(const hx_gf32x4*)(wsrc + boff[j]);
+#endif
+    frag(sArow, sBu + 2 * TAPB, K2{}, af0, bf0);
+    mfma_tap(af1, bf1);
+    HX2P_SEG();
+    mfma_tap(af0, bf0);
+    __syncthreads();
+    ++gidx;
+  };
   auto unit = [&](int c, auto u_tag) {
     constexpr int U = decltype(u_tag)::value;
     const char* sAc = smemp + (c & 1) * abytes;
@@ -601,8 +688,19 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
 #endif
     ++gidx;
   };
+  int c0 = 0;
+#if RGFM_HX2P_FAST
+  if (gn_on && nitems >= 3) {
 #pragma unroll 1
-  for (int c = 0; c < nmain; ++c) {
+    for (; c0 < nmain - 1; ++c0) {
+      unit_fast(c0, U0{});
+      unit_fast(c0, U1{});
+      unit_fast(c0, U2{});
+    }
+  }
+#endif
+#pragma unroll 1
+  for (int c = c0; c < nmain; ++c) {
     unit(c, U0{});
     unit(c, U1{});
     unit(c, U2{});

@@ -195,7 +195,7 @@ int main(int argc, char** argv) {
 #endif
   hipEvent_t e0, e1;
   hipEventCreate(&e0), hipEventCreate(&e1);
-  const int reps = 20;
+  const int reps = getenv("REPS") ? atoi(getenv("REPS")) : 20;
   hipEventRecord(e0);
   for (int i = 0; i < reps; ++i) launch();
   hipEventRecord(e1);
