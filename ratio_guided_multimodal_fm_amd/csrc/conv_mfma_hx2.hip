@@ -14,7 +14,7 @@
 // |a'| >= 32768 and the host re-runs the call on the split-bf16 kernel (fp32 range); convs whose
 // weights fall outside [2^-40, 2^40] are never routed here (launch_pack_conv_hx2 reports it).
 //
-// Same fusion set, tiling, prologue (consumer-side GroupNorm) and epilogue as conv_mfma_hx2_kernel.
+// Same fusion set, tiling, prologue (consumer-side GroupNorm) and epilogue as conv_mfma_bx3w_kernel.
 // LDS records are 2 planes x 16 fp16 = 64 B; the four 16-byte slots of a record are XOR-swizzled with
 // (record >> 2) & 3, so 16 consecutive records cover all 16 slot columns of the 256-byte bank row
 // (conflict-free ds_read_b128).  DESIGN.md section 4 has the measurements.
@@ -27,13 +27,15 @@
 namespace rgfm {
 
 // ------------------------------------------------------------------------------------
-// Workgroup = 512 threads = 2 waves per SIMD (one wave alone cannot keep the bf16 MFMA pipe issuing
+// Workgroup = 512 threads = 2 waves per SIMD (one wave alone cannot keep the 16-bit MFMA pipe issuing
 // back to back), built as TWO of conv_mfma_pf_kernel's 4-wave tiles sharing one operand in LDS:
 //   PAIRN  (Cout % (64 NT) == 0): one 256-pixel tile x two adjacent 32NT-channel groups -- the
 //          activation halo (the expensive GroupNorm+SiLU+split staging) is staged once for both;
 //   !PAIRN: two consecutive 256-pixel tiles x one channel group -- the weights are staged once.
-// LDS records are unpadded (96 B) with the two 16-byte halves of a plane swapped on odd groups of
-// 8 records, which keeps ds_read_b128 conflict-free for 16 consecutive records.
+// LDS records are unpadded (64 B: two planes x 16 fp16) with their four 16-byte slots XOR-swizzled
+// (conv_hx2_common.h: hswz), which keeps ds_read_b128 conflict-free for 16 consecutive records.
+// The stride-1 / upsampling convs run on conv_mfma_hx2p.hip's pipelined version of this kernel; this one
+// keeps the stride-2 and transposed modes and the external scale/shift array path.
 // ------------------------------------------------------------------------------------
 #ifdef RGFM_HX2_PROF
 __device__ unsigned long long g_hx2_prof[10];  // prologue, issue, mfma, commit-wait, commit-A, commit-B, epilogue, blocks, [8] shader clk, [9] 100 MHz ticks
