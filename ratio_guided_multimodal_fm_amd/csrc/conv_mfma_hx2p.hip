@@ -35,6 +35,12 @@ namespace rgfm {
 #ifndef RGFM_HX2P_FAST
 #define RGFM_HX2P_FAST 1
 #endif
+#ifndef RGFM_HX2P_GNEARLY
+#define RGFM_HX2P_GNEARLY 0  // (1: request the first channel's partials at the top of the kernel -- measured: no gain, more live registers)
+#endif
+#ifndef RGFM_HX2P_TAIL
+#define RGFM_HX2P_TAIL 1
+#endif
 #ifndef RGFM_HX2P_PRIO
 #define RGFM_HX2P_PRIO 0
 #endif
@@ -158,6 +164,49 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
   const bool sample_ok = bw < a.B;
   const size_t pix0 = (g.spt == 1) ? (size_t)b0 * HW + (size_t)row0 * W : (size_t)bw * HW;
   const float qmain = a.hq[0];
+  // ---- GroupNorm prologue, part 1: which (row, group, channel) this lane reduces, and the request for the first
+  // channel's partials -- they fly during the accumulator set-up and the item decode (part 2 is further down)
+  constexpr int NW = NTHR / 64;
+  const int gn_cin = a.C0 + a.C1;
+  const int gn_rows = NA * g.spt;                       // 1, 2, 4 or 8 (<= NW)
+  const int gn_cpg = gn_cin >> 3;
+  // log2 of the waves per row (all powers of two): as many as it takes to give every lane ONE channel (a round trip
+  // per channel is what the time goes into), never more -- measured: with 8-channel groups the one-wave-per-row
+  // form is 3-5 % faster per layer (fewer waves fetching and reducing in fp64), at 32-channel groups four waves
+  // per row are 3 % faster
+  int gn_wsh = (31 - __builtin_clz(NW)) - (31 - __builtin_clz(gn_rows));
+  {
+    const int need = gn_cpg <= 8 ? 0 : (gn_cpg <= 16 ? 1 : (gn_cpg <= 32 ? 2 : 3));
+    gn_wsh = gn_wsh < need ? gn_wsh : need;
+  }
+  const int gn_row = wave >> gn_wsh, gn_part = wave & ((1 << gn_wsh) - 1);
+  const bool gn_active = gn_row < gn_rows;  // (wave-uniform: the waves past the last row sit this out)
+  const int gn_lpg = 8 << gn_wsh;                       // lanes per group = 64 / (8 / WPR)
+  const int gn_gl = lane >> (3 + gn_wsh), gn_sub = lane & (gn_lpg - 1);
+  const int gn_gi = gn_part * (8 >> gn_wsh) + gn_gl;    // group of this lane
+  const int gn_kmax = (gn_cpg + gn_lpg - 1) / gn_lpg;   // channels per lane (wave-uniform, <= 4)
+  const int gn_b = ((g.spt == 1 ? gn_row : (gn_row >> 2)) ? tb0_[1] : tb0_[0]) + (g.spt == 1 ? 0 : (gn_row & 3));
+  const bool gn_bok = gn_active && gn_b < a.B;
+  float2 gn_v[16];
+  float gn_gv = 0.f, gn_bv = 0.f;
+  int gn_npt = 0;
+  auto gn_fetch = [&](int k) {
+    const int c = gn_gi * gn_cpg + gn_sub + gn_lpg * k;
+    const bool have = gn_bok && gn_sub + gn_lpg * k < gn_cpg;
+    const bool first = !have || c < a.C0;  // (no k-th channel: entry 0 of the first source, never used)
+    const float* st = first ? a.gn_stats0 : a.gn_stats1;
+    const int cs = first ? a.C0 : a.C1, cc = have ? (first ? c : c - a.C0) : 0;
+    const int npt = first ? a.gn_nparts0 : a.gn_g.nparts;
+    const size_t bb = gn_bok ? (size_t)gn_b : 0;
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+      gn_v[p] = *reinterpret_cast<const float2*>(st + ((bb * npt + (p < npt ? p : 0)) * cs + cc) * 2);
+    gn_gv = a.gn_gamma[have ? c : 0], gn_bv = a.gn_beta[have ? c : 0];
+    gn_npt = npt;
+  };
+#if RGFM_HX2P_GNEARLY
+  if (a.gn_stats0 && gn_active) gn_fetch(0);
+#endif
   PPROF_T(tkx);
   f32x16 acc[2][NT];
   // bias (+ skip bias + time embedding) and, for an identity residual, the RAW residual values go into the
@@ -344,62 +393,47 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
   };
 
   PPROF_T(tkb);
-  if (a.gn_stats0) {
-    // ---- consumer-side GroupNorm: scale/shift of this block's sample(s) from the producers' partial statistics,
-    // before chunk 0's prefetch registers come alive (with them the partials would spill).  Wave w owns table row
-    // w (= ga * spt + s, the slot of smask); lane = group * 8 + sub, sub strides over the group's channels; all of a
-    // lane's <= 4 x 16 partials are fetched in one round trip, reduced in fp64 without divisions in the loop:
+  if (a.gn_stats0 && gn_active) {
+    // ---- consumer-side GroupNorm: scale/shift of this block's sample(s) from the producers' partial statistics.
+    // Up to all waves take part: the block's R = NA * spt table rows (one per sample slot) are split over the NW waves,
+    // WPR = NW / R waves per row, each wave GPW = 8 / WPR of the row's 8 groups, LPG = 64 / GPW lanes per group; a lane
+    // strides over its group's channels (sub, sub + LPG, ...), fetches the <= 16 partials of a channel in one
+    // round trip (the first channel's were requested at the top of the kernel: gn_fetch(0)) and reduces
     //   N = sum n_p, S1 = sum n_p mean_p, S2 = sum [M2_p + n_p mean_p^2]  ->  mean = S1 / N, var = S2 / N - mean^2
-    if (wave < NA * g.spt) {
-      const int ga = (g.spt == 1) ? wave : (wave >> 2), sl = (g.spt == 1) ? 0 : (wave & 3);
-      const int b = (ga ? tb0_[1] : tb0_[0]) + sl;
-      const TileGeom gg = a.gn_g;
-      const int cpg = cin >> 3, gi = lane >> 3, sub = lane & 7;
-      float gam[4], bet[4];
-      const bool bok = b < a.B;
-      double n = 0.0, s1 = 0.0, s2 = 0.0;
-      const int kmax = (cpg + 7) >> 3;  // channels per lane (wave-uniform)
+    // in fp64 without divisions in the loop; an LPG-lane butterfly gives the group's sums.
+    float gam[4], bet[4];
+    double n = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll 1
-      for (int k = 0; k < kmax; ++k) {  // one channel (16 partials) per round trip: more at once spills
-        const int c = gi * cpg + sub + 8 * k;
-        const bool have = bok && sub + 8 * k < cpg;
-        const bool first = !have || c < a.C0;  // (no k-th channel: entry 0 of the first source, never used)
-        const float* st = first ? a.gn_stats0 : a.gn_stats1;
-        const int cs = first ? a.C0 : a.C1, cc = have ? (first ? c : c - a.C0) : 0;
-        const int npt = first ? a.gn_nparts0 : gg.nparts;
-        const size_t bb = bok ? (size_t)b : 0;
-        float2 v[16];
+    for (int k = 0; k < gn_kmax; ++k) {
+      if (k > 0 || !RGFM_HX2P_GNEARLY) gn_fetch(k);
+      if (k == 0) gam[0] = gn_gv, bet[0] = gn_bv;
+      else if (k == 1) gam[1] = gn_gv, bet[1] = gn_bv;
+      else if (k == 2) gam[2] = gn_gv, bet[2] = gn_bv;
+      else gam[3] = gn_gv, bet[3] = gn_bv;
+      const bool have = gn_bok && gn_sub + gn_lpg * k < gn_cpg;
+      const int npt = gn_npt;
 #pragma unroll
-        for (int p = 0; p < 16; ++p)
-          v[p] = *reinterpret_cast<const float2*>(st + ((bb * npt + (p < npt ? p : 0)) * cs + cc) * 2);
-        const float gv = a.gn_gamma[have ? c : 0], bv = a.gn_beta[have ? c : 0];
-        if (k == 0) gam[0] = gv, bet[0] = bv;
-        else if (k == 1) gam[1] = gv, bet[1] = bv;
-        else if (k == 2) gam[2] = gv, bet[2] = bv;
-        else gam[3] = gv, bet[3] = bv;
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-          const double np = (have && p < npt) ? (double)geom_part_count(gg, p % gg.nparts) : 0.0;
-          const double mp = (double)v[p].x;
-          n += np;
-          s1 += np * mp;
-          s2 += np > 0.0 ? (double)v[p].y + np * mp * mp : 0.0;
-        }
+      for (int p = 0; p < 16; ++p) {
+        const double np = (have && p < npt) ? (double)geom_part_count(a.gn_g, p % a.gn_g.nparts) : 0.0;
+        const double mp = (double)gn_v[p].x;
+        n += np;
+        s1 += np * mp;
+        s2 += np > 0.0 ? (double)gn_v[p].y + np * mp * mp : 0.0;
       }
-      n = sub_sum(n), s1 = sub_sum(s1), s2 = sub_sum(s2);
-      const double mean = n > 0.0 ? s1 / n : 0.0;
-      const double var = n > 0.0 ? s2 / n - mean * mean : 0.0;
-      const float gm = (float)mean;
-      const float rstd = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + 1e-5));
+    }
+    for (int o = 1; o < gn_lpg; o <<= 1) n += __shfl_xor(n, o), s1 += __shfl_xor(s1, o), s2 += __shfl_xor(s2, o);
+    const double mean = n > 0.0 ? s1 / n : 0.0;
+    const double var = n > 0.0 ? s2 / n - mean * mean : 0.0;
+    const float gm = (float)mean;
+    const float rstd = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + 1e-5));
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (sub + 8 * k < cpg) {
-          const float sc = rstd * gam[k];
-          float2 o;
-          o.x = HX_SA * sc;
-          o.y = HX_SA * (bet[k] - gm * sc);
-          *reinterpret_cast<float2*>(sTab + ((size_t)wave * cin + gi * cpg + sub + 8 * k) * 2) = o;
-        }
+    for (int k = 0; k < 4; ++k) {
+      if (gn_sub + gn_lpg * k < gn_cpg) {
+        const float sc = rstd * gam[k];
+        float2 o;
+        o.x = HX_SA * sc;
+        o.y = HX_SA * (bet[k] - gm * sc);
+        *reinterpret_cast<float2*>(sTab + ((size_t)gn_row * cin + gn_gi * gn_cpg + gn_sub + gn_lpg * k) * 2) = o;
       }
     }
     // (visible to every wave after the barrier that opens commit(0))
@@ -648,6 +682,35 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
     __syncthreads();
     ++gidx;
   };
+  // the last chunk of a conv without 1x1-skip chunks: nothing is left to stage but the weights of its own units
+  // (unit g + 1 while U < 2, fetch of unit g + 2 while U < 1), so the three units are MFMA streams
+  auto unit_tail = [&](int c, auto u_tag) {
+    constexpr int U = decltype(u_tag)::value;
+    const char* sArow = smemp + (c & 1) * abytes + U * WR * HRW;
+    const char* sBu = sB + (gidx & 1) * UB;
+    f16x8 af0[2][2], bf0[NT][2], af1[2][2], bf1[NT][2];
+    frag(sArow, sBu, K0{}, af0, bf0);
+    HX2P_SEG();
+    frag(sArow, sBu + TAPB, K1{}, af1, bf1);
+    mfma_tap(af0, bf0);
+    HX2P_SEG();
+    if (U < 2) {
+      char* sBn = sB + ((gidx + 1) & 1) * UB;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) *reinterpret_cast<f32x4*>(sBn + boff[j]) = rb[j];
+    }
+    if (U < 1) {
+      const char* wsrc = wpk + (size_t)(gidx + 2) * UB;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) rb[j] = *(const hx_gf32x4*)(wsrc + boff[j]);
+    }
+    frag(sArow, sBu + 2 * TAPB, K2{}, af0, bf0);
+    mfma_tap(af1, bf1);
+    HX2P_SEG();
+    mfma_tap(af0, bf0);
+    if (U < 2) __syncthreads();
+    ++gidx;
+  };
   auto unit = [&](int c, auto u_tag) {
     constexpr int U = decltype(u_tag)::value;
     const char* sAc = smemp + (c & 1) * abytes;
@@ -696,6 +759,12 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
       unit_fast(c0, U0{});
       unit_fast(c0, U1{});
       unit_fast(c0, U2{});
+    }
+    if (RGFM_HX2P_TAIL && nskip == 0) {
+      unit_tail(c0, U0{});
+      unit_tail(c0, U1{});
+      unit_tail(c0, U2{});
+      ++c0;
     }
   }
 #endif
