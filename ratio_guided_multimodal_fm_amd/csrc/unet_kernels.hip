@@ -133,9 +133,14 @@ void launch_conv_in(const ConvInArgs& a, int cin, hipStream_t s) {
 // update x <- x + v*dt (src/sample_mnist_svhn.py:174-175) optionally fused.
 // thread = output pixel; the transformed input chunk is staged in LDS exactly as
 // in conv_mfma; the weights are wave-uniform (scalar loads).
+// HBM-bound (reads [B,H,W,Cin] once): the halo items of a thread are decoded once per block, every chunk's fetches
+// are unconditional (clamped) loads issued together, and the fetches of chunk c + 1 are in flight while chunk c is
+// multiplied -- the first version fetched each item under a per-item branch inside stage_input's loop, which
+// serialises the round trips (hipcc waits for a load under a branch before leaving the iteration).
 template <int CIMG>
 __global__ __launch_bounds__(256) void conv_out_kernel(const ConvOutArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int MAXI = 7;  // halo items (pixel, 4 channels) per thread: halo_px <= 448
   const int tid = threadIdx.x;
   const TileGeom g = a.g;
   const int W = g.W, H = g.H, HW = g.HW;
@@ -167,15 +172,79 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const ConvOutArgs a) {
   const int r = q / W, x = q - r * W;
   const int abase = ((s * HR + r) * WR + x) * LDP;
 
+  // per item: source offset (floats, clamped to 0 when outside), scale/shift offset, LDS offset, flags
+  const int nitem = a.halo_px * 4;
+  const int nit = (nitem + 255) >> 8;  // block-uniform
+  unsigned poff[MAXI];  // (float index into the activation: B H W Cin < 2^32)
+  int aoff[MAXI], ldst[MAXI];
+  unsigned okm = 0u;
+  {
+    const int per = HR * WR;
+#pragma unroll
+    for (int j = 0; j < MAXI; ++j) {
+      const int it = tid + 256 * j;
+      poff[j] = 0, aoff[j] = 0, ldst[j] = -1;
+      if (it < nitem) {
+        const int hp = it >> 2, qq = it & 3;
+        const int ss = hp / per;
+        const int rem = hp - ss * per;
+        const int hy = rem / WR, hx = rem - hy * WR;
+        const int b = b0 + ss, y = row0 + hy - 1, xx = hx - 1;
+        ldst[j] = hp * LDP + qq * 4;
+        if ((y >= 0) && (y < H) && (xx >= 0) && (xx < W) && (b < a.B)) {
+          okm |= 1u << j;
+          poff[j] = (unsigned)((b * H + y) * W + xx) * (unsigned)a.Cin + (unsigned)(qq * 4);
+          aoff[j] = (b * a.Cin + qq * 4) * 2;
+        }
+      }
+    }
+  }
+  // scale/shift pairs: with one sample per tile (spt == 1: every 32x32 / 28x28 map) they depend on the thread's channel
+  // quad only (it & 3 == tid & 3 for all its items) -- one fetch per chunk; several samples per tile: per item, at commit
+  f32x4 ra[MAXI], re0, re1;
+  const bool one_b = g.spt == 1;
+  const int aoff1 = ((b0 < a.B ? b0 : 0) * a.Cin + (tid & 3) * 4) * 2;
+  auto issue = [&](int ch) {
+#pragma unroll
+    for (int j = 0; j < MAXI; ++j)
+      if (j < nit) ra[j] = *reinterpret_cast<const f32x4*>(a.in + (size_t)poff[j] + ch * KC);
+    if (a.ab && one_b) {
+      const f32x4* pp = reinterpret_cast<const f32x4*>(a.ab + (size_t)aoff1 + ch * KC * 2);
+      re0 = pp[0], re1 = pp[1];
+    }
+  };
+  auto commit = [&](int ch) {
+#pragma unroll
+    for (int j = 0; j < MAXI; ++j)
+      if (j < nit) {
+        f32x4 v = ra[j];
+        if (a.ab) {
+          f32x4 e0 = re0, e1 = re1;
+          if (!one_b) {
+            const f32x4* pp = reinterpret_cast<const f32x4*>(a.ab + (size_t)aoff[j] + ch * KC * 2);
+            e0 = pp[0], e1 = pp[1];
+          }
+          v.x = silu_fast(e0.x * v.x + e0.y);
+          v.y = silu_fast(e0.z * v.y + e0.w);
+          v.z = silu_fast(e1.x * v.z + e1.y);
+          v.w = silu_fast(e1.z * v.w + e1.w);
+        }
+        if (!((okm >> j) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ldst[j] >= 0) *reinterpret_cast<f32x4*>(smem + ldst[j]) = v;
+      }
+  };
+
   float acc[CIMG];
 #pragma unroll
   for (int co = 0; co < CIMG; ++co) acc[co] = 0.f;
 
-  for (int ch = 0; ch < a.Cin / KC; ++ch) {
+  const int nch = a.Cin / KC;
+  issue(0);
+  for (int ch = 0; ch < nch; ++ch) {
     __syncthreads();
-    stage_input<CONV_S1>(smem, a.in, nullptr, a.Cin, 0, H, W, a.ab, ch * KC, a.B, b0, row0, H, W, HR,
-                         WR, a.halo_px, tid, 256);
+    commit(ch);
     __syncthreads();
+    if (ch + 1 < nch) issue(ch + 1);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int ky = tap / 3, kx = tap - 3 * ky;

@@ -62,25 +62,41 @@ def main():
     # (MNIST32 net then SVHN net) at batch B
     start = len(rows) - per_step
     seq = rows[start:start + per_step]
-    tot_fl = tot_t = 0.0
-    agg = defaultdict(lambda: [0.0, 0.0])
-    print(f"{'layer':16s} {'S':>3s} {'cin':>4s} {'cout':>4s} {'grid':>10s} {'us':>8s} {'TF/s':>7s}")
+    tot_fl = tot_t = tot_roof = tot_by = 0.0
+    agg = defaultdict(lambda: [0.0, 0.0, 0.0])
+    # per-layer roofline against the MEASURED ceilings of the bench line (roofline.measured_ceilings): the f16-MFMA
+    # loop / 3 products, and the float4 copy rate; bytes = input + residual or skip source + output, once each
+    mf = float(sys.argv[3]) if len(sys.argv) > 3 else 565.0   # TFLOP/s fp32-equivalent
+    bw = float(sys.argv[4]) if len(sys.argv) > 4 else 4.5     # TB/s
+    print(f"{'layer':16s} {'S':>3s} {'cin':>4s} {'cout':>4s} {'grid':>10s} {'us':>8s} {'TF/s':>7s} {'MB':>6s} {'roof us':>8s} {'bound':>5s} {'frac':>5s}")
     # launch order inside a step: SVHN net first (side stream), then the MNIST net
     for (name, mode, S, cin, cout, sk), (t0, t1, kn, gx, gy) in zip([("s." + a[0],) + a[1:] for a in sv] +
                                                                       [("m." + a[0],) + a[1:] for a in mn], seq):
         fl = 2.0 * B * S * S * cout * (9 * cin + sk)
         us = (t1 - t0) / 1e3
+        s_in = S if mode == 0 else (2 * S if mode == 1 else S // 2)
+        by = 4.0 * B * (s_in * s_in * cin + S * S * cout)
+        if name.endswith(".conv2"):
+            by += 4.0 * B * S * S * (sk if sk else cout)  # 1x1-skip source, or the identity residual
+        t_m, t_h = fl / (mf * 1e6), by / (bw * 1e6)
+        roof = max(t_m, t_h)
         tot_fl += fl
         tot_t += us
+        tot_roof += roof
+        tot_by += by
         agg[(S, mode)][0] += fl
         agg[(S, mode)][1] += us
-        print(f"{name:16s} {S:3d} {cin:4d} {cout:4d} {gx:6d}x{gy:<3d} {us:8.1f} {fl / us / 1e6:7.1f}")
+        agg[(S, mode)][2] += roof
+        print(f"{name:16s} {S:3d} {cin:4d} {cout:4d} {gx:6d}x{gy:<3d} {us:8.1f} {fl / us / 1e6:7.1f} {by / 1e6:6.0f} {roof:8.1f} "
+              f"{'mfma' if t_m >= t_h else 'hbm':>5s} {roof / us:5.2f}")
     print(f"step total: {tot_fl / 1e12:.3f} TFLOP in {tot_t / 1e3:.2f} ms = {tot_fl / tot_t / 1e6:.1f} TF/s")
+    print(f"per-layer roofline (max of {mf:.0f} TFLOP/s fp32-equivalent and {bw:.2f} TB/s, both measured): {tot_roof / 1e3:.2f} ms "
+          f"-> the step runs at {tot_roof / tot_t:.2f} of it; algorithmic bytes {tot_by / 1e9:.2f} GB")
     span = (seq[-1][1] - seq[0][0]) / 1e6
     print(f"wall span of these launches: {span:.2f} ms")
     for k in sorted(agg):
-        fl, us = agg[k]
-        print(f"  S={k[0]:2d} mode={k[1]}: {us / 1e3:7.2f} ms  {fl / us / 1e6:6.1f} TF/s  ({100 * us / tot_t:.1f}% of conv time)")
+        fl, us, roof = agg[k]
+        print(f"  S={k[0]:2d} mode={k[1]}: {us / 1e3:7.2f} ms  {fl / us / 1e6:6.1f} TF/s  ({100 * us / tot_t:.1f}% of conv time)  {roof / us:.2f} of its roofline")
 
 
 if __name__ == "__main__":
