@@ -316,6 +316,11 @@ def main():
                           "launches overlap; sum_launch_ms double-counts that time; RGFM_OVERLAP=0 serialises)",
                 "kernel_time_share": conv_ms * 1e-3 / elapsed,
             }
+            lt = os.path.join(ROOT, "profiles", "r02_bench_layers_serial.txt")
+            if os.path.exists(lt) and conv_mode == "hx2":
+                # (static pointer, not a live number) rocprofv3 per-layer table of one main-loop step with every layer's
+                # own roofline max(MFMA ceiling, HBM copy rate): a third of the step is memory-bound, DESIGN.md 4
+                line["roofline"]["per_layer_table"] = os.path.relpath(lt, ROOT)
             if ceilings:
                 line["roofline"]["measured_ceilings"] = {
                     "mfma_f16_tflops": ceilings["mfma_f16_tflops"], "hbm_copy_gbs": ceilings["hbm_copy_gbs"],
