@@ -125,84 +125,103 @@ __device__ __forceinline__ float wave_max_g(float v) {
   return v;
 }
 
-// grid (ceil(B/4), ceil(D/1024)); one launch per modality (part).
-__global__ __launch_bounds__(256) void guid_apply_kernel(const GuidanceArgs a_in, int part) {
+// Importance weights of one row per wave (sample_mnist_svhn.py:146-156), written once per step to a.wbuf [B][N]
+// (and to weights_out when the caller asks for them): guid_apply's workgroups -- sixteen column blocks per row
+// block -- read them back instead of each recomputing the softmax from the distance slices.
+__global__ __launch_bounds__(256) void guid_weights_kernel(const GuidanceArgs a_in) {
   const GuidanceArgs a = with_schedule(a_in);
   extern __shared__ __attribute__((aligned(16))) float sw[];  // [4][N]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int N = a.N;
-  const int b0 = blockIdx.x * 4;
-  {  // importance weights of row b0 + wave (sample_mnist_svhn.py:146-156)
-    const int b = b0 + wave;
-    if (b < a.B) {
-      float mx = -INFINITY;
-      for (int i = lane; i < N; i += 64) {
-        const float l = logp_of(a, b, i);
-        sw[wave * N + i] = l;
-        mx = fmaxf(mx, l);
-      }
-      mx = wave_max_g(mx);
-      float ps = 0.f, zs = 0.f;
-      for (int i = lane; i < N; i += 64) {
-        const float p = expf(sw[wave * N + i] - mx);
-        sw[wave * N + i] = p;
-        ps += p;
-        zs += __fmul_rn(a.mc_ratios[i], p);
-      }
-      ps = wave_sum_g(ps);
-      zs = wave_sum_g(zs);
-      const float pbar = __fadd_rn(ps / (float)N, 1e-10f);
-      const float zbar = __fadd_rn(zs / (float)N, 1e-10f);
-      float ws = 0.f;
-      for (int i = lane; i < N; i += 64) {
-        const float w = __fmul_rn(a.mc_ratios[i] / zbar, sw[wave * N + i] / pbar);
-        sw[wave * N + i] = w;
-        ws += w;
-      }
-      ws = __fadd_rn(wave_sum_g(ws), 1e-10f);
-      for (int i = lane; i < N; i += 64) {
-        const float w = sw[wave * N + i] / ws;
-        sw[wave * N + i] = w;
-        if (a.weights_out && part == 0 && blockIdx.y == 0) a.weights_out[(size_t)b * N + i] = w;
-      }
-    } else {
-      for (int i = lane; i < N; i += 64) sw[wave * N + i] = 0.f;
-    }
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= a.B) return;
+  float* swr = sw + (size_t)wave * N;
+  float mx = -INFINITY;
+  for (int i = lane; i < N; i += 64) {
+    const float l = logp_of(a, b, i);
+    swr[i] = l;
+    mx = fmaxf(mx, l);
   }
-  __syncthreads();
+  mx = wave_max_g(mx);
+  float ps = 0.f, zs = 0.f;
+  for (int i = lane; i < N; i += 64) {
+    const float p = expf(swr[i] - mx);
+    swr[i] = p;
+    ps += p;
+    zs += __fmul_rn(a.mc_ratios[i], p);
+  }
+  ps = wave_sum_g(ps);
+  zs = wave_sum_g(zs);
+  const float pbar = __fadd_rn(ps / (float)N, 1e-10f);
+  const float zbar = __fadd_rn(zs / (float)N, 1e-10f);
+  float ws = 0.f;
+  for (int i = lane; i < N; i += 64) {
+    const float w = __fmul_rn(a.mc_ratios[i] / zbar, swr[i] / pbar);
+    swr[i] = w;
+    ws += w;
+  }
+  ws = __fadd_rn(wave_sum_g(ws), 1e-10f);
+  for (int i = lane; i < N; i += 64) {
+    const float w = swr[i] / ws;
+    a.wbuf[(size_t)b * N + i] = w;
+    if (a.weights_out) a.weights_out[(size_t)b * N + i] = w;
+  }
+}
+
+// grid (ceil(B/16), ceil(D/256)); one launch per modality (part).  Wave w owns rows b0 + 4w .. + 3 (their weights sit
+// in a wave-private piece of LDS: no workgroup barrier), lane l the four components d0 + 4l .. + 3.  The four waves
+// of a workgroup stream the same 256-wide column block of the MC set, so it leaves L2 once per 16 rows, and the grid
+// has 512 workgroups at the benchmark shape (the first version: 4 rows x 1024 columns per workgroup, 128
+// workgroups, weights recomputed by every one of them).  Arithmetic and summation order are unchanged.
+template <int RW>  // rows per wave: 4 (16 rows per workgroup; N <= 1024), or 1 for larger MC sets (LDS: [4 RW][N] floats)
+__global__ __launch_bounds__(256) void guid_apply_kernel(const GuidanceArgs a_in, int part) {
+  const GuidanceArgs a = with_schedule(a_in);
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [4 RW][N]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = a.N;
+  const int b0 = blockIdx.x * (4 * RW) + wave * RW;
+  float* swv = sw + (size_t)wave * RW * N;
+#pragma unroll
+  for (int r = 0; r < RW; ++r)
+    for (int i = lane; i < N; i += 64) swv[r * N + i] = (b0 + r < a.B) ? a.wbuf[(size_t)(b0 + r) * N + i] : 0.f;
+  // (wave-private LDS: the lanes of this wave wrote what they now read; LDS operations of a wave execute in order)
 
   const float* X = part ? a.y : a.x;
   const float* M = part ? a.mc_y1 : a.mc_x1;
   float* V = part ? a.vy : a.vx;
   float* XS = part ? a.y_state : a.x_state;
   const int D = part ? a.dy : a.dx;
-  const int d = blockIdx.y * 1024 + tid * 4;
+  const int d = blockIdx.y * 256 + lane * 4;
   if (d >= D) return;
-  f32x4 xv[4], g[4];
+  f32x4 xv[RW], g[RW];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < RW; ++r) {
     g[r] = f32x4{0.f, 0.f, 0.f, 0.f};
     xv[r] = (b0 + r < a.B) ? *reinterpret_cast<const f32x4*>(X + (size_t)(b0 + r) * D + d) : g[r];
   }
+  // (m - x) / (1 - t + eps) of the reference (sample_mnist_svhn.py:159) as a multiplication by the correctly rounded
+  // reciprocal: one more rounding (<= 1 ulp per term) for a loop that was 70 % division instructions
+  const float rcden = 1.0f / a.cden;
   for (int i = 0; i < N; ++i) {
-    float w[4];
+    float w[RW];
+    bool any = false;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) w[r] = sw[r * N + i];
+    for (int r = 0; r < RW; ++r) w[r] = swv[r * N + i], any = any || (w[r] != 0.f);
     // exact skip: a zero weight contributes +0 to every sum
-    if (w[0] == 0.f && w[1] == 0.f && w[2] == 0.f && w[3] == 0.f) continue;
+    if (!any) continue;
     const f32x4 m = *reinterpret_cast<const f32x4*>(M + (size_t)i * D + d);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < RW; ++r) {
       if (w[r] != 0.f) {
-        g[r].x = __fadd_rn(g[r].x, __fmul_rn(w[r], (m.x - xv[r].x) / a.cden));
-        g[r].y = __fadd_rn(g[r].y, __fmul_rn(w[r], (m.y - xv[r].y) / a.cden));
-        g[r].z = __fadd_rn(g[r].z, __fmul_rn(w[r], (m.z - xv[r].z) / a.cden));
-        g[r].w = __fadd_rn(g[r].w, __fmul_rn(w[r], (m.w - xv[r].w) / a.cden));
+        g[r].x = __fadd_rn(g[r].x, __fmul_rn(w[r], __fmul_rn(m.x - xv[r].x, rcden)));
+        g[r].y = __fadd_rn(g[r].y, __fmul_rn(w[r], __fmul_rn(m.y - xv[r].y, rcden)));
+        g[r].z = __fadd_rn(g[r].z, __fmul_rn(w[r], __fmul_rn(m.z - xv[r].z, rcden)));
+        g[r].w = __fadd_rn(g[r].w, __fmul_rn(w[r], __fmul_rn(m.w - xv[r].w, rcden)));
       }
     }
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < RW; ++r) {
     if (b0 + r >= a.B) continue;
     const size_t o = (size_t)(b0 + r) * D + d;
     const f32x4 v = *reinterpret_cast<const f32x4*>(V + o);
@@ -230,9 +249,16 @@ void launch_guid_logp(const GuidanceArgs& a, hipStream_t s) {
 }
 
 void launch_guid_apply(const GuidanceArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)4 * a.N * sizeof(float);
-  hipLaunchKernelGGL(guid_apply_kernel, dim3((a.B + 3) / 4, (a.dx + 1023) / 1024), dim3(256), lds, s, a, 0);
-  hipLaunchKernelGGL(guid_apply_kernel, dim3((a.B + 3) / 4, (a.dy + 1023) / 1024), dim3(256), lds, s, a, 1);
+  hipLaunchKernelGGL(guid_weights_kernel, dim3((a.B + 3) / 4), dim3(256), (size_t)4 * a.N * sizeof(float), s, a);
+  if ((size_t)16 * a.N * sizeof(float) <= 64 * 1024) {
+    const size_t lds = (size_t)16 * a.N * sizeof(float);
+    hipLaunchKernelGGL(guid_apply_kernel<4>, dim3((a.B + 15) / 16, (a.dx + 255) / 256), dim3(256), lds, s, a, 0);
+    hipLaunchKernelGGL(guid_apply_kernel<4>, dim3((a.B + 15) / 16, (a.dy + 255) / 256), dim3(256), lds, s, a, 1);
+  } else {  // (N <= 4096: rgfm_guidance_apply / the samplers check)
+    const size_t lds = (size_t)4 * a.N * sizeof(float);
+    hipLaunchKernelGGL(guid_apply_kernel<1>, dim3((a.B + 3) / 4, (a.dx + 255) / 256), dim3(256), lds, s, a, 0);
+    hipLaunchKernelGGL(guid_apply_kernel<1>, dim3((a.B + 3) / 4, (a.dy + 255) / 256), dim3(256), lds, s, a, 1);
+  }
 }
 
 // x <- x + v * dt (mul, then add: two roundings like the reference's x_t + v * dt)

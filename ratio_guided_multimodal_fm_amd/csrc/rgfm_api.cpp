@@ -963,8 +963,11 @@ extern "C" int rgfm_sample_single(rgfm_unet* h, float* x_inout, int batch, int n
   return RGFM_OK;
 }
 
-static size_t guid_scratch_bytes(int batch, int n_mc) {  // sliced fp64 distances, RGFM_GUID_SLICES slices at most
+static size_t guid_dist_bytes(int batch, int n_mc) {  // sliced fp64 distances, RGFM_GUID_SLICES slices at most
   return (((size_t)RGFM_GUID_SLICES * batch * (n_mc > 0 ? n_mc : 1) * sizeof(double)) + 255) & ~(size_t)255;
+}
+static size_t guid_scratch_bytes(int batch, int n_mc) {  // + the step's importance weights [B][N]
+  return guid_dist_bytes(batch, n_mc) + ((((size_t)batch * (n_mc > 0 ? n_mc : 1) * sizeof(float)) + 255) & ~(size_t)255);
 }
 
 extern "C" int rgfm_guidance_workspace_bytes(int batch, int n_mc, size_t* bytes) {
@@ -997,6 +1000,7 @@ int guidance_launch(const float* x, const float* y, float* vx, float* vy, const 
   a.sched = sched, a.step_ptr = sched ? step_ptr : nullptr;
   a.g1 = (float)(1.0 - gamma), a.g2 = (float)gamma;
   a.dist = reinterpret_cast<double*>(logp), a.weights_out = weights_out, a.x_state = xs, a.y_state = ys, a.dt = dt;
+  a.wbuf = reinterpret_cast<float*>(reinterpret_cast<char*>(logp) + guid_dist_bytes(B, N));
   a.slice_len = 1024;  // 1024-element slices unless that needs more than RGFM_GUID_SLICES of them
   while ((dx + a.slice_len - 1) / a.slice_len + (dy + a.slice_len - 1) / a.slice_len > RGFM_GUID_SLICES) a.slice_len *= 2;
   a.nsx = (dx + a.slice_len - 1) / a.slice_len, a.nsy = (dy + a.slice_len - 1) / a.slice_len;

@@ -285,6 +285,7 @@ struct GuidanceArgs {
   const float* sched;
   const int* step_ptr;
   float* weights_out;  // optional [B][N]
+  float* wbuf;         // [B][N] importance weights of the step (scratch: behind the distance slices)
   float* x_state;      // optional fused Euler: x_state += dt * blended
   float* y_state;
   float dt;
