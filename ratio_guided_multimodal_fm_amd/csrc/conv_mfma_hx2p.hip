@@ -59,11 +59,15 @@ __device__ long long g_hx2p_trace[2][64][9];  // block 3, waves 0 and 4: per uni
 // halo is staged once for both groups; HX2P_FOUR_WAVES: 4 waves = one tile x one group, 256 threads and at most 80 KB
 // of LDS, so that TWO workgroups share a CU and one's prologue / epilogue (memory round trips, every CU at once)
 // could run under the other's K loop (an experiment for the short-K layers, built only with -DRGFM_HX2P_W4_VARIANT).
-enum { HX2P_TWO_TILES = 0, HX2P_PAIRN = 1, HX2P_FOUR_WAVES = 2 };
+// HX2P_PAIRN_HALF: as HX2P_PAIRN with 32-channel groups (NT = 1): one tile x 64 of a 128-channel weight block, twice the
+// workgroups -- for launches that would otherwise leave CUs without a workgroup (the 8x8 level, small batches).
+enum { HX2P_TWO_TILES = 0, HX2P_PAIRN = 1, HX2P_FOUR_WAVES = 2, HX2P_PAIRN_HALF = 3 };
 
 template <int NT, int MODE, int CFG>
 __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a, const int num_tiles) {
-  constexpr bool PAIRN = CFG == HX2P_PAIRN;
+  constexpr bool PAIRN = CFG == HX2P_PAIRN || CFG == HX2P_PAIRN_HALF;
+  constexpr bool HALF = CFG == HX2P_PAIRN_HALF;  // the packed weight blocks hold 128 channels, this workgroup takes 64 of them
+  static_assert(!HALF || NT == 1, "HX2P_PAIRN_HALF: 2 groups x 32 channels");
   constexpr bool W4 = CFG == HX2P_FOUR_WAVES;
   constexpr int NTHR = W4 ? 256 : 512;
 
@@ -318,17 +322,24 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
   const int nskip = (a.res_mode == 2) ? (a.R0 + a.R1) / KC : 0;  // 1x1-skip chunks (one tap each)
   const int ntot = nmain + nskip;
   const int G = 3 * nmain + nskip;                              // units
-  const char* wpk = reinterpret_cast<const char*>(a.wpkh) + (size_t)blockIdx.y * nmain * 9 * TAPB;
-  const char* wsk = reinterpret_cast<const char*>(a.wskiph) + (size_t)blockIdx.y * nskip * TAPB;
+  // packed weights: [channel block][chunk][tap] slabs of TAPS bytes (TAPS = TAPB, or 2 TAPB when this workgroup takes
+  // half of a 128-channel block: then a tap's slab holds this half at offset whalf)
+  constexpr int TAPS = HALF ? 2 * TAPB : TAPB;
+  constexpr int UBS = 3 * TAPS;
+  const int wblk = HALF ? (int)blockIdx.y >> 1 : (int)blockIdx.y;
+  const int whalf = HALF ? ((int)blockIdx.y & 1) * TAPB : 0;
+  const char* wpk = reinterpret_cast<const char*>(a.wpkh) + (size_t)wblk * nmain * 9 * TAPS + whalf;
+  const char* wsk = reinterpret_cast<const char*>(a.wskiph) + (size_t)wblk * nskip * TAPS + whalf;
 
   f32x4 ra[MAXIT], rb[NB];
   // byte offset of this thread's j-th 16-byte weight item of a 3-tap unit; threads past the unit's last item repeat an
   // earlier one (same bytes to the same address), so the fast path below copies without per-lane predicates
-  int boff[NB];
+  int boff[NB], soff[NB];  // (LDS image offset, source offset inside the unit's three slabs)
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int it = tid + NTHR * j;
     boff[j] = (it < UB / 16 ? it : it - UB / 16) * 16;
+    soff[j] = HALF ? (boff[j] / TAPB) * TAPS + (boff[j] % TAPB) : boff[j];
   }
   // range flag: the largest |fp16| (as a bit pattern, per 16-bit half) this thread has stored; >= 0x7800 is |a'| >= 32768
   typedef unsigned short hx_u16x2 __attribute__((ext_vector_type(2)));
@@ -374,12 +385,12 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
   // weights of unit gg: the packed image is the LDS byte image, a linear 16-byte copy (a skip unit is one tap)
   auto issue_b = [&](int gg) {
     const bool main = gg < 3 * nmain;
-    const char* src = main ? wpk + (size_t)gg * UB : wsk + (size_t)(gg - 3 * nmain) * TAPB;
+    const char* src = main ? wpk + (size_t)gg * UBS : wsk + (size_t)(gg - 3 * nmain) * TAPS;
     const int nit = main ? UB / 16 : TAPB / 16;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int it = tid + NTHR * j;
-      rb[j] = *(const hx_gf32x4*)(src + (main ? boff[j] : (it < nit ? it : 0) * 16));  // (main: as the fast unit fetches)
+      rb[j] = *(const hx_gf32x4*)(src + (main ? soff[j] : (it < nit ? it : 0) * 16));  // (main: as the fast unit fetches)
     }
   };
   auto commit_b = [&](int gg) {
@@ -644,7 +655,7 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
     const char* sArow = smemp + (c & 1) * abytes + U * WR * HRW;
     const char* sBu = sB + (gidx & 1) * UB;
     char* sBn = sB + ((gidx + 1) & 1) * UB;
-    const char* wsrc = wpk + (size_t)(gidx + 2) * UB;
+    const char* wsrc = wpk + (size_t)(gidx + 2) * UBS;
     f16x8 af0[2][2], bf0[NT][2], af1[2][2], bf1[NT][2];
     frag(sArow, sBu, K0{}, af0, bf0);
     const int c2 = c + 2 < ntot ? c + 2 : ntot - 1;  // (no such chunk: a harmless re-fetch, never committed)
@@ -673,7 +684,7 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
     for (int k = 0; k < NU; ++k)
       if (k == 0 || U + 3 * k < nitems) issue_a(dn, U + 3 * k);
 #pragma unroll
-    for (int j = 0; j < NB; ++j) rb[j] = *(const hx_gf32x4*)(wsrc + boff[j]);
+    for (int j = 0; j < NB; ++j) rb[j] = *(const hx_gf32x4*)(wsrc + soff[j]);
 #endif
     frag(sArow, sBu + 2 * TAPB, K2{}, af0, bf0);
     mfma_tap(af1, bf1);
@@ -700,9 +711,9 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
       for (int j = 0; j < NB; ++j) *reinterpret_cast<f32x4*>(sBn + boff[j]) = rb[j];
     }
     if (U < 1) {
-      const char* wsrc = wpk + (size_t)(gidx + 2) * UB;
+      const char* wsrc = wpk + (size_t)(gidx + 2) * UBS;
 #pragma unroll
-      for (int j = 0; j < NB; ++j) rb[j] = *(const hx_gf32x4*)(wsrc + boff[j]);
+      for (int j = 0; j < NB; ++j) rb[j] = *(const hx_gf32x4*)(wsrc + soff[j]);
     }
     frag(sArow, sBu + 2 * TAPB, K2{}, af0, bf0);
     mfma_tap(af1, bf1);
@@ -885,8 +896,8 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
 // ---------------------------------------------------------------- host side
 static int hx2p_halo(const ConvArgs& a) { return a.g.spt * (a.g.th + 2) * (a.g.W + 2); }
 static size_t hx2p_lds_bytes(const ConvArgs& a, int cfg) {
-  const int nt = (a.Cout % 64 == 0) ? 2 : 1;
-  const int na = cfg == HX2P_TWO_TILES ? 2 : 1, nbt = 32 * nt * (cfg == HX2P_PAIRN ? 2 : 1);
+  const int nt = (cfg == HX2P_PAIRN_HALF) ? 1 : ((a.Cout % 64 == 0) ? 2 : 1);
+  const int na = cfg == HX2P_TWO_TILES ? 2 : 1, nbt = 32 * nt * ((cfg == HX2P_PAIRN || cfg == HX2P_PAIRN_HALF) ? 2 : 1);
   size_t bytes = (size_t)2 * (na * hx2p_halo(a) + 1) * HRW + (size_t)2 * 3 * nbt * HRW;  // two halo buffers (+ pad record) + two weight units
   if (a.gn_stats0) bytes += (size_t)(na * a.g.spt + 1) * (a.C0 + a.C1) * 2 * sizeof(float);  // scale/shift table + the zero row
   bytes += (size_t)(a.C0 + a.C1 + (a.res_mode == 2 ? a.R0 + a.R1 : 0));                    // 16 bytes per 16-channel chunk: descriptors
@@ -898,13 +909,19 @@ static size_t hx2p_lds_bytes(const ConvArgs& a, int cfg) {
 // RGFM_HX2P_W4 = 1 (layers with Cout % 128 != 0) or 2 (every layer whose LDS need allows two workgroups per CU).
 static int g_hx2p_w4 = 0;
 void conv_hx2p_set_w4(int v) { g_hx2p_w4 = v; }
+// launches of 128-channel workgroups with fewer workgroups than this take HX2P_PAIRN_HALF (0: never); the CU count
+static int g_hx2p_half = 256;
+void conv_hx2p_set_half(int v) { g_hx2p_half = v; }
 static int hx2p_cfg(const ConvArgs& a) {
 #ifdef RGFM_HX2P_W4_VARIANT
   const bool fits = hx2p_lds_bytes(a, HX2P_FOUR_WAVES) <= 80 * 1024;  // two workgroups per CU
   if (g_hx2p_w4 == 2 && fits) return HX2P_FOUR_WAVES;
   if (g_hx2p_w4 == 1 && fits && a.Cout % 128 != 0) return HX2P_FOUR_WAVES;
 #endif
-  return (a.Cout % 128 == 0) ? HX2P_PAIRN : HX2P_TWO_TILES;
+  if (a.Cout % 128 != 0) return HX2P_TWO_TILES;
+  // fewer workgroups than CUs: 64-channel workgroups, twice as many
+  const int wgs = geom_num_tiles(a.g, a.B) * (a.Cout / 128);
+  return (g_hx2p_half && wgs < g_hx2p_half) ? HX2P_PAIRN_HALF : HX2P_PAIRN;
 }
 
 // the pipelined kernel takes: stride-1 / upsampling convs whose input norm (if any) is the consumer-side one
@@ -923,6 +940,7 @@ int conv_hx2p_init() {
   RAISEP(1, CONV_S1, HX2P_TWO_TILES); RAISEP(1, CONV_UP2, HX2P_TWO_TILES);
   RAISEP(2, CONV_S1, HX2P_TWO_TILES); RAISEP(2, CONV_UP2, HX2P_TWO_TILES);
   RAISEP(2, CONV_S1, HX2P_PAIRN); RAISEP(2, CONV_UP2, HX2P_PAIRN);
+  RAISEP(1, CONV_S1, HX2P_PAIRN_HALF); RAISEP(1, CONV_UP2, HX2P_PAIRN_HALF);
 #ifdef RGFM_HX2P_W4_VARIANT
   RAISEP(1, CONV_S1, HX2P_FOUR_WAVES); RAISEP(1, CONV_UP2, HX2P_FOUR_WAVES);
   RAISEP(2, CONV_S1, HX2P_FOUR_WAVES); RAISEP(2, CONV_UP2, HX2P_FOUR_WAVES);
@@ -937,7 +955,9 @@ void launch_conv_hx2p(const ConvArgs& a_in, int mode, hipStream_t s) {
   const int nt = (a.Cout % 64 == 0) ? 2 : 1;
   const int tiles = geom_num_tiles(a.g, a.B);
   const int cfg = hx2p_cfg(a);
-  dim3 grid(cfg == HX2P_TWO_TILES ? (tiles + 1) / 2 : tiles, cfg == HX2P_PAIRN ? a.Cout / 128 : a.Cout / (32 * nt), 1);
+  if (cfg == HX2P_PAIRN_HALF) a.fin_expected *= 2;  // (producer-side finalize: twice the 4-wave groups along the channels arrive)
+  dim3 grid(cfg == HX2P_TWO_TILES ? (tiles + 1) / 2 : tiles,
+            cfg == HX2P_PAIRN ? a.Cout / 128 : (cfg == HX2P_PAIRN_HALF ? a.Cout / 64 : a.Cout / (32 * nt)), 1);
   const size_t lds = hx2p_lds_bytes(a, cfg);
 #define LAUNCHP(NTV, M, P) hipLaunchKernelGGL((conv_mfma_hx2p_kernel<NTV, M, P>), grid, dim3(P == HX2P_FOUR_WAVES ? 256 : 512), lds, s, a, tiles)
 #define LAUNCHM(NTV, P)                           \
@@ -946,6 +966,7 @@ void launch_conv_hx2p(const ConvArgs& a_in, int mode, hipStream_t s) {
     else LAUNCHP(NTV, CONV_UP2, P);               \
   } while (0)
   if (cfg == HX2P_PAIRN) LAUNCHM(2, HX2P_PAIRN);
+  else if (cfg == HX2P_PAIRN_HALF) LAUNCHM(1, HX2P_PAIRN_HALF);
 #ifdef RGFM_HX2P_W4_VARIANT
   else if (cfg == HX2P_FOUR_WAVES) {
     if (nt == 2) LAUNCHM(2, HX2P_FOUR_WAVES);

@@ -295,6 +295,7 @@ int ensure_init() {
       return fail(RGFM_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, dev) == hipSuccess) d.num_cus = p.multiProcessorCount;
+    conv_hx2p_set_half(d.num_cus);  // launches with fewer 128-channel workgroups than CUs take 64-channel workgroups
     HIP_TRY(hipStreamCreateWithFlags(&d.side, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&d.fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&d.join, hipEventDisableTiming));

@@ -211,6 +211,7 @@ void launch_conv_hx2(const ConvArgs& a, int mode, hipStream_t s);
 // producer / consumer pipelined version for CONV_S1 / CONV_UP2 (conv_mfma_hx2p.hip); same arguments
 bool conv_hx2p_supported(const ConvArgs& a, int mode);
 int conv_hx2p_init();
+void conv_hx2p_set_half(int v);  // workgroup-count threshold of the 64-channel configuration (0: never; default 256 = CUs)
 void conv_hx2p_set_w4(int v);  // tools/kbench only (-DRGFM_HX2P_W4_VARIANT): 1 / 2 = four-wave workgroups, see conv_mfma_hx2p.hip
 void launch_conv_hx2p(const ConvArgs& a, int mode, hipStream_t s);
 // packs w (mode CONV_S1: [Cout][Cin][taps]; CONV_S2: the phase-major stride-2 order; CONV_T2: a ConvTranspose2d

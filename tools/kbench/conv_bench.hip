@@ -63,6 +63,7 @@ int main(int argc, char** argv) {
   conv_hx2_init();
   conv_hx2p_init();
   if (getenv("RGFM_HX2P_W4")) conv_hx2p_set_w4(atoi(getenv("RGFM_HX2P_W4")));
+  if (getenv("RGFM_HX2P_HALF")) conv_hx2p_set_half(atoi(getenv("RGFM_HX2P_HALF")));
 
   ConvArgs a{};
   a.in0 = dev_rand((size_t)B * Sin * Sin * Cin, 1.f, 1);
