@@ -58,7 +58,8 @@ __device__ long long g_hx2p_trace[2][64][9];  // block 3, waves 0 and 4: per uni
 // weights are staged once for both tiles; HX2P_PAIRN: 8 waves = one tile x two channel groups (Cout % 128 == 0), the
 // halo is staged once for both groups; HX2P_FOUR_WAVES: 4 waves = one tile x one group, 256 threads and at most 80 KB
 // of LDS, so that TWO workgroups share a CU and one's prologue / epilogue (memory round trips, every CU at once)
-// could run under the other's K loop (an experiment for the short-K layers, built only with -DRGFM_HX2P_W4_VARIANT).
+// could run under the other's K loop -- measured: it does not, so it is used for what it is good at:
+// under-filled launches, where one tile per workgroup means twice the workgroups.
 // HX2P_PAIRN_HALF: as HX2P_PAIRN with 32-channel groups (NT = 1): one tile x 64 of a 128-channel weight block, twice the
 // workgroups -- for launches that would otherwise leave CUs without a workgroup (the 8x8 level, small batches).
 enum { HX2P_TWO_TILES = 0, HX2P_PAIRN = 1, HX2P_FOUR_WAVES = 2, HX2P_PAIRN_HALF = 3 };
@@ -903,24 +904,29 @@ static size_t hx2p_lds_bytes(const ConvArgs& a, int cfg) {
   bytes += (size_t)(a.C0 + a.C1 + (a.res_mode == 2 ? a.R0 + a.R1 : 0));                    // 16 bytes per 16-channel chunk: descriptors
   return bytes;
 }
-// The four-wave configuration is a measured dead end on this workload (a four-wave workgroup takes as long
-// as an eight-wave one, co-resident or not; whole bench 438 vs 450 paired images/s with it on the Cin <= 32 layers),
-// so the library does not instantiate it; tools/kbench builds it with -DRGFM_HX2P_W4_VARIANT and selects it with
-// RGFM_HX2P_W4 = 1 (layers with Cout % 128 != 0) or 2 (every layer whose LDS need allows two workgroups per CU).
+// Under-filled launches (fewer workgroups than CUs: the 8x8 level, the MC pre-phase, the per-rank shapes of a
+// multi-GPU run) are cut finer: 128-channel workgroups into two 64-channel ones (HX2P_PAIRN_HALF), two-tile workgroups
+// into two four-wave ones (HX2P_FOUR_WAVES) -- a workgroup's time is set by its serial chain of round trips, not by
+// its MFMA count, so twice the workgroups on idle CUs is up to twice the rate (measured -15..-34 % per launch).
+// On FULL launches both are slower (four-wave workgroups: a four-wave workgroup takes as long as an eight-wave one
+// co-resident or not, whole bench 438 vs 450 img/s; 64-channel workgroups: +20 % time), so only below g_hx2p_half.
+// tools/kbench: RGFM_HX2P_W4 = 1 / 2 forces four-wave workgroups (layers with Cout % 128 != 0 / every layer whose
+// LDS need allows two workgroups per CU), RGFM_HX2P_HALF sets the threshold.
 static int g_hx2p_w4 = 0;
 void conv_hx2p_set_w4(int v) { g_hx2p_w4 = v; }
-// launches of 128-channel workgroups with fewer workgroups than this take HX2P_PAIRN_HALF (0: never); the CU count
+// launches with fewer workgroups than this are cut finer (0: never); the CU count
 static int g_hx2p_half = 256;
 void conv_hx2p_set_half(int v) { g_hx2p_half = v; }
 static int hx2p_cfg(const ConvArgs& a) {
-#ifdef RGFM_HX2P_W4_VARIANT
   const bool fits = hx2p_lds_bytes(a, HX2P_FOUR_WAVES) <= 80 * 1024;  // two workgroups per CU
   if (g_hx2p_w4 == 2 && fits) return HX2P_FOUR_WAVES;
   if (g_hx2p_w4 == 1 && fits && a.Cout % 128 != 0) return HX2P_FOUR_WAVES;
-#endif
-  if (a.Cout % 128 != 0) return HX2P_TWO_TILES;
-  // fewer workgroups than CUs: 64-channel workgroups, twice as many
-  const int wgs = geom_num_tiles(a.g, a.B) * (a.Cout / 128);
+  const int tiles = geom_num_tiles(a.g, a.B);
+  if (a.Cout % 128 != 0) {
+    const int wgs = ((tiles + 1) / 2) * (a.Cout / (32 * ((a.Cout % 64 == 0) ? 2 : 1)));
+    return (g_hx2p_half && wgs < g_hx2p_half) ? HX2P_FOUR_WAVES : HX2P_TWO_TILES;
+  }
+  const int wgs = tiles * (a.Cout / 128);
   return (g_hx2p_half && wgs < g_hx2p_half) ? HX2P_PAIRN_HALF : HX2P_PAIRN;
 }
 
@@ -941,10 +947,8 @@ int conv_hx2p_init() {
   RAISEP(2, CONV_S1, HX2P_TWO_TILES); RAISEP(2, CONV_UP2, HX2P_TWO_TILES);
   RAISEP(2, CONV_S1, HX2P_PAIRN); RAISEP(2, CONV_UP2, HX2P_PAIRN);
   RAISEP(1, CONV_S1, HX2P_PAIRN_HALF); RAISEP(1, CONV_UP2, HX2P_PAIRN_HALF);
-#ifdef RGFM_HX2P_W4_VARIANT
   RAISEP(1, CONV_S1, HX2P_FOUR_WAVES); RAISEP(1, CONV_UP2, HX2P_FOUR_WAVES);
   RAISEP(2, CONV_S1, HX2P_FOUR_WAVES); RAISEP(2, CONV_UP2, HX2P_FOUR_WAVES);
-#endif
 #undef RAISEP
   return rc;
 }
@@ -967,12 +971,10 @@ void launch_conv_hx2p(const ConvArgs& a_in, int mode, hipStream_t s) {
   } while (0)
   if (cfg == HX2P_PAIRN) LAUNCHM(2, HX2P_PAIRN);
   else if (cfg == HX2P_PAIRN_HALF) LAUNCHM(1, HX2P_PAIRN_HALF);
-#ifdef RGFM_HX2P_W4_VARIANT
   else if (cfg == HX2P_FOUR_WAVES) {
     if (nt == 2) LAUNCHM(2, HX2P_FOUR_WAVES);
     else LAUNCHM(1, HX2P_FOUR_WAVES);
   }
-#endif
   else {
     if (nt == 2) LAUNCHM(2, HX2P_TWO_TILES);
     else LAUNCHM(1, HX2P_TWO_TILES);

@@ -211,8 +211,8 @@ void launch_conv_hx2(const ConvArgs& a, int mode, hipStream_t s);
 // producer / consumer pipelined version for CONV_S1 / CONV_UP2 (conv_mfma_hx2p.hip); same arguments
 bool conv_hx2p_supported(const ConvArgs& a, int mode);
 int conv_hx2p_init();
-void conv_hx2p_set_half(int v);  // workgroup-count threshold of the 64-channel configuration (0: never; default 256 = CUs)
-void conv_hx2p_set_w4(int v);  // tools/kbench only (-DRGFM_HX2P_W4_VARIANT): 1 / 2 = four-wave workgroups, see conv_mfma_hx2p.hip
+void conv_hx2p_set_half(int v);  // launches with fewer workgroups than this are cut finer (0: never; the CU count)
+void conv_hx2p_set_w4(int v);  // tools/kbench A/B: 1 / 2 = four-wave workgroups forced, see conv_mfma_hx2p.hip
 void launch_conv_hx2p(const ConvArgs& a, int mode, hipStream_t s);
 // packs w (mode CONV_S1: [Cout][Cin][taps]; CONV_S2: the phase-major stride-2 order; CONV_T2: a ConvTranspose2d
 // weight [Cin][Cout][4][4], taps ignored) and writes the scale record hq[4] (device)
