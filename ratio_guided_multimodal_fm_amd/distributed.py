@@ -47,11 +47,19 @@ class HipBackend:
         return _engine.sample_pair(fm_x, fm_y, x, y, mc_x1, mc_y1, mc_ratios, num_steps, gamma)
 
 
+def _via_host(t, group):
+    """gloo group + device tensor (the two-ranks-on-one-GPU test, or a CPU-only fabric): the collective runs on a
+    host copy.  RCCL groups never take this path."""
+    return t.is_cuda and dist.is_initialized() and dist.get_backend(group) == "gloo"
+
+
 def _all_gather_rows(t, counts, group):
     """all_gather of row-sharded tensors with possibly unequal row counts."""
     world = len(counts)
     if not dist.is_initialized():
         return t
+    if _via_host(t, group):
+        return _all_gather_rows(t.cpu(), counts, group).to(t.device)
     mx = max(counts)
     if t.shape[0] < mx:
         pad = torch.zeros((mx - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
@@ -119,6 +127,9 @@ def sharded_paired_sampler(fm_x, fm_y, ratio_estimator, guidance_method, guidanc
 
 
 def _gather_rows(t, counts, group, rank, dst=0):
+    if _via_host(t, group):
+        out = _gather_rows(t.cpu(), counts, group, rank, dst)
+        return None if out is None else out.to(t.device)
     world = len(counts)
     mx = max(counts)
     if t.shape[0] < mx:

@@ -311,3 +311,36 @@ def test_cli_sample28_from_checkpoint_files(dev, tmp_path, monkeypatch):
                                      device=dev, mc_batch_size=4)
     vals = list(saved.values())
     assert torch.equal(vals[0], xs.cpu()) and torch.equal(vals[1], ys.cpu())
+
+
+def _two_rank_worker(rank, world, port, out_dir):
+    """One of two processes sharing cuda:0: HIP compute per rank, gloo collectives (RCCL refuses two ranks on one
+    device, and the box has one GPU)."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ratio_guided_multimodal_fm_amd.distributed import sharded_paired_sampler
+    dev = torch.device("cuda:0")
+    fm, fs, rr = make_module("mnist32", dev), make_module("svhn", dev), make_module("ratio_ms", dev)
+    noise = paired_noise(77, 37, 24, (1, 32, 32), (3, 32, 32))  # uneven shards: 19 + 18 rows, 12 + 12 MC rows
+    x, y = sharded_paired_sampler(fm, fs, rr, "mc_feng", 0.5, 12, noise, dev, gather="all")
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), x=x.cpu().numpy(), y=y.cpu().numpy())
+    dist.destroy_process_group()
+
+
+def test_two_ranks_hip_compute_equal_single_process(dev, tmp_path):
+    """world_size 2 with the HIP library as compute backend (two processes on the one GPU, gloo for the two
+    collectives): sharded MC pre-phase, all_gather of the MC set, sharded guided loop, all_gather of the outputs --
+    bit-identical to the single-process HIP run (rows are independent given the MC set, and a row's arithmetic does
+    not depend on how many rows share its launch)."""
+    import torch.multiprocessing as mp
+    from ratio_guided_multimodal_fm_amd.distributed import sharded_paired_sampler
+    mp.spawn(_two_rank_worker, args=(2, 29581, str(tmp_path)), nprocs=2, join=True)
+    fm, fs, rr = make_module("mnist32", dev), make_module("svhn", dev), make_module("ratio_ms", dev)
+    noise = paired_noise(77, 37, 24, (1, 32, 32), (3, 32, 32))
+    x1, y1 = sharded_paired_sampler(fm, fs, rr, "mc_feng", 0.5, 12, noise, dev)
+    for r in range(2):
+        g = np.load(tmp_path / f"r{r}.npz")
+        assert np.array_equal(g["x"], x1.cpu().numpy()) and np.array_equal(g["y"], y1.cpu().numpy())
