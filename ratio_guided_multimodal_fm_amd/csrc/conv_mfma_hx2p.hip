@@ -1,4 +1,4 @@
-// conv_mfma_hx2p.hip -- pipelined, staggered version of conv_mfma_hx2_kernel for the stride-1 and upsampling convs
+// conv_mfma_hx2p.hip -- pipelined version of conv_mfma_hx2_kernel for the stride-1 and upsampling convs
 // (CONV_S1, CONV_UP2: 96 % of the conv time of a U-Net evaluation).  Same arithmetic (two scaled fp16 planes, three
 // f16-MFMA products per fp32 product), same tiling, prologue and epilogue; the K loop is re-cut so that the matrix
 // pipe of a SIMD always has one of its two waves to feed it:
@@ -13,6 +13,12 @@
 //     (w, w+4) are therefore always in opposite phases: one wave's GroupNorm/SiLU/split VALU work and memory
 //     instructions issue while the other wave's MFMAs occupy the matrix pipe, instead of both staging and then both
 //     multiplying as in conv_mfma_hx2_kernel (where the pipe idles 55 % of the time).
+//   * FAST units (chunks 0 .. nmain - 2 of every conv with the consumer-side GroupNorm, i.e. nearly all of them;
+//     unit_fast below): the staging instructions sit BETWEEN the three taps' MFMAs in one straight-line stream, so a
+//     wave's unit time is max(MFMA, everything else) instead of their sum; TAIL units (the last chunk of a conv
+//     without 1x1-skip chunks) are MFMA streams.  The staggered form remains for the last chunk with skip chunks
+//     behind it, the skip chunks themselves and convs without an input norm.
+//   * Under-filled launches are cut into twice the workgroups (HX2P_PAIRN_HALF, HX2P_FOUR_WAVES: see CFG below).
 //
 // Tried before this and rejected (tools/experiments/conv_mfma_hx2_prodcons.hip, numbers in DESIGN.md): four dedicated
 // producer waves (one per SIMD) beside eight MFMA waves, weights and raw activations by LDS-DMA.  A lone wave is
