@@ -344,3 +344,19 @@ def test_two_ranks_hip_compute_equal_single_process(dev, tmp_path):
     for r in range(2):
         g = np.load(tmp_path / f"r{r}.npz")
         assert np.array_equal(g["x"], x1.cpu().numpy()) and np.array_equal(g["y"], y1.cpu().numpy())
+
+
+@pytest.mark.parametrize("tag", ["mnist32", "svhn"])
+def test_rows_do_not_depend_on_the_launch_shape(dev, tag):
+    """A row's result is bitwise the same whether its launch is full or under-filled: at 512 rows the convs run as
+    two-tile / 128-channel workgroups, at 8 rows (and for the 8x8 level at 512) as four-wave / 64-channel ones
+    (conv_mfma_hx2p.hip: hx2p_cfg) -- same arithmetic, same summation order per output element."""
+    m = make_module(tag, dev)
+    cin = 1 if tag == "mnist32" else 3
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(512, cin, 32, 32, generator=g).to(dev)
+    t = torch.rand(512, generator=g).to(dev)
+    full = m(x, t)
+    for lo, hi in ((0, 8), (250, 263), (500, 512)):
+        part = m(x[lo:hi].contiguous(), t[lo:hi].contiguous())
+        assert torch.equal(part, full[lo:hi]), (tag, lo, hi, float((part - full[lo:hi]).abs().max()))
