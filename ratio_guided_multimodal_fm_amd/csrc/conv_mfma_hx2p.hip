@@ -71,7 +71,10 @@ __device__ long long g_hx2p_trace[2][64][9];  // block 3, waves 0 and 4: per uni
 enum { HX2P_TWO_TILES = 0, HX2P_PAIRN = 1, HX2P_FOUR_WAVES = 2, HX2P_PAIRN_HALF = 3 };
 
 template <int NT, int MODE, int CFG>
-__global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a, const int num_tiles) {
+#ifndef RGFM_HX2P_QEXP
+#define RGFM_HX2P_QEXP 0  // (kbench experiment: NT = 1 one-tile x 64-channel workgroups at four waves per SIMD, two workgroups per CU)
+#endif
+__global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, (RGFM_HX2P_QEXP && NT == 1 && CFG == HX2P_PAIRN) ? 4 : 2) void conv_mfma_hx2p_kernel(const ConvArgs a, const int num_tiles) {
   constexpr bool PAIRN = CFG == HX2P_PAIRN || CFG == HX2P_PAIRN_HALF;
   constexpr bool HALF = CFG == HX2P_PAIRN_HALF;  // the packed weight blocks hold 128 channels, this workgroup takes 64 of them
   static_assert(!HALF || NT == 1, "HX2P_PAIRN_HALF: 2 groups x 32 channels");
@@ -771,7 +774,7 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
   };
   int c0 = 0;
 #if RGFM_HX2P_FAST
-  if (gn_on && nitems >= 3) {
+  if (!(RGFM_HX2P_QEXP && NT == 1 && CFG == HX2P_PAIRN) && gn_on && nitems >= 3) {
 #pragma unroll 1
     for (; c0 < nmain - 1; ++c0) {
       unit_fast(c0, U0{});
@@ -902,8 +905,10 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
 
 // ---------------------------------------------------------------- host side
 static int hx2p_halo(const ConvArgs& a) { return a.g.spt * (a.g.th + 2) * (a.g.W + 2); }
+static int g_hx2p_q = 0;  // RGFM_HX2P_QEXP builds: Cout == 64 layers as NT = 1 HX2P_PAIRN workgroups
+void conv_hx2p_set_q(int v) { g_hx2p_q = v; }
 static size_t hx2p_lds_bytes(const ConvArgs& a, int cfg) {
-  const int nt = (cfg == HX2P_PAIRN_HALF) ? 1 : ((a.Cout % 64 == 0) ? 2 : 1);
+  const int nt = (cfg == HX2P_PAIRN_HALF || (RGFM_HX2P_QEXP && g_hx2p_q && cfg == HX2P_PAIRN && a.Cout == 64)) ? 1 : ((a.Cout % 64 == 0) ? 2 : 1);
   const int na = cfg == HX2P_TWO_TILES ? 2 : 1, nbt = 32 * nt * ((cfg == HX2P_PAIRN || cfg == HX2P_PAIRN_HALF) ? 2 : 1);
   size_t bytes = (size_t)2 * (na * hx2p_halo(a) + 1) * HRW + (size_t)2 * 3 * nbt * HRW;  // two halo buffers (+ pad record) + two weight units
   if (a.gn_stats0) bytes += (size_t)(na * a.g.spt + 1) * (a.C0 + a.C1) * 2 * sizeof(float);  // scale/shift table + the zero row
@@ -928,6 +933,7 @@ static int hx2p_cfg(const ConvArgs& a) {
   if (g_hx2p_w4 == 2 && fits) return HX2P_FOUR_WAVES;
   if (g_hx2p_w4 == 1 && fits && a.Cout % 128 != 0) return HX2P_FOUR_WAVES;
   const int tiles = geom_num_tiles(a.g, a.B);
+  if (RGFM_HX2P_QEXP && g_hx2p_q && a.Cout == 64) return HX2P_PAIRN;
   if (a.Cout % 128 != 0) {
     const int wgs = ((tiles + 1) / 2) * (a.Cout / (32 * ((a.Cout % 64 == 0) ? 2 : 1)));
     return (g_hx2p_half && wgs < g_hx2p_half) ? HX2P_FOUR_WAVES : HX2P_TWO_TILES;
@@ -952,6 +958,9 @@ int conv_hx2p_init() {
   RAISEP(1, CONV_S1, HX2P_TWO_TILES); RAISEP(1, CONV_UP2, HX2P_TWO_TILES);
   RAISEP(2, CONV_S1, HX2P_TWO_TILES); RAISEP(2, CONV_UP2, HX2P_TWO_TILES);
   RAISEP(2, CONV_S1, HX2P_PAIRN); RAISEP(2, CONV_UP2, HX2P_PAIRN);
+#if RGFM_HX2P_QEXP
+  RAISEP(1, CONV_S1, HX2P_PAIRN); RAISEP(1, CONV_UP2, HX2P_PAIRN);
+#endif
   RAISEP(1, CONV_S1, HX2P_PAIRN_HALF); RAISEP(1, CONV_UP2, HX2P_PAIRN_HALF);
   RAISEP(1, CONV_S1, HX2P_FOUR_WAVES); RAISEP(1, CONV_UP2, HX2P_FOUR_WAVES);
   RAISEP(2, CONV_S1, HX2P_FOUR_WAVES); RAISEP(2, CONV_UP2, HX2P_FOUR_WAVES);
@@ -975,6 +984,12 @@ void launch_conv_hx2p(const ConvArgs& a_in, int mode, hipStream_t s) {
     if (mode == CONV_S1) LAUNCHP(NTV, CONV_S1, P); \
     else LAUNCHP(NTV, CONV_UP2, P);               \
   } while (0)
+#if RGFM_HX2P_QEXP
+  if (cfg == HX2P_PAIRN && a.Cout == 64) {
+    grid = dim3(tiles, 1, 1);
+    LAUNCHM(1, HX2P_PAIRN);
+  } else
+#endif
   if (cfg == HX2P_PAIRN) LAUNCHM(2, HX2P_PAIRN);
   else if (cfg == HX2P_PAIRN_HALF) LAUNCHM(1, HX2P_PAIRN_HALF);
   else if (cfg == HX2P_FOUR_WAVES) {

@@ -214,6 +214,12 @@ int conv_hx2p_init();
 void conv_hx2p_set_half(int v);  // launches with fewer workgroups than this are cut finer (0: never; the CU count)
 void conv_hx2p_set_w4(int v);  // tools/kbench A/B: 1 / 2 = four-wave workgroups forced, see conv_mfma_hx2p.hip
 void launch_conv_hx2p(const ConvArgs& a, int mode, hipStream_t s);
+// four-waves-per-SIMD version (conv_mfma_hx2q.hip: one tile x 64 channels per workgroup, two workgroups per CU) for
+// full launches over 16- / 32-pixel-wide rasters with Cout % 64 == 0; bit-identical results
+bool conv_hx2q_supported(const ConvArgs& a, int mode);
+int conv_hx2q_init();
+void conv_hx2q_set_min(int v);  // launches with fewer workgroups than this stay on conv_mfma_hx2p_kernel (0: never used)
+void launch_conv_hx2q(const ConvArgs& a, int mode, hipStream_t s);
 // packs w (mode CONV_S1: [Cout][Cin][taps]; CONV_S2: the phase-major stride-2 order; CONV_T2: a ConvTranspose2d
 // weight [Cin][Cout][4][4], taps ignored) and writes the scale record hq[4] (device)
 void launch_pack_conv_hx2(const float* w, void* out, float* hq, int Cout, int Cin, int taps, int mode, hipStream_t s);

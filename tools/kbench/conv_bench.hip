@@ -1,5 +1,5 @@
 // Single-layer benchmark of the conv kernels (development tool; not part of the library).
-//   conv_bench <S> <Cin> <Cout> [mode 0|2] [res 0|1|2] [B] [which: bx3|f32|hx2|hx2p]
+//   conv_bench <S> <Cin> <Cout> [mode 0|2] [res 0|1|2] [B] [which: bx3|f32|hx2|hx2p|hx2q]
 // Every run also checks the selected kernel against the exact-fp32 MFMA kernel on the same data.
 // Builds one ConvArgs with random NHWC input / packed weights, launches it 20x, prints us and
 // fp32-equivalent TFLOP/s; with -DRGFM_BX3_PROF also the per-phase cycle counts of the bx3w kernel.
@@ -14,6 +14,7 @@
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma.hip"
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2.hip"
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2p.hip"
+#include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2q.hip"
 #include "../../ratio_guided_multimodal_fm_amd/csrc/unet_kernels.hip"
 
 using namespace rgfm;
@@ -55,6 +56,7 @@ int main(int argc, char** argv) {
   const bool f32 = argc > 7 && strcmp(argv[7], "f32") == 0;
   const bool hx2 = argc > 7 && strcmp(argv[7], "hx2") == 0;
   const bool hx2p = argc > 7 && strcmp(argv[7], "hx2p") == 0;
+  const bool hx2q = argc > 7 && strcmp(argv[7], "hx2q") == 0;
   const int Sin = mode == CONV_UP2 ? S / 2 : S;
   const int nt = Cout % 64 == 0 ? 2 : 1;
   CK(hipSetDevice(0));
@@ -62,8 +64,13 @@ int main(int argc, char** argv) {
   conv_bx3_init();
   conv_hx2_init();
   conv_hx2p_init();
+  conv_hx2q_init();
+  if (getenv("RGFM_HX2Q_MIN")) conv_hx2q_set_min(atoi(getenv("RGFM_HX2Q_MIN")));
   if (getenv("RGFM_HX2P_W4")) conv_hx2p_set_w4(atoi(getenv("RGFM_HX2P_W4")));
   if (getenv("RGFM_HX2P_HALF")) conv_hx2p_set_half(atoi(getenv("RGFM_HX2P_HALF")));
+#if RGFM_HX2P_QEXP
+  if (getenv("RGFM_HX2P_Q")) conv_hx2p_set_q(atoi(getenv("RGFM_HX2P_Q")));
+#endif
 
   ConvArgs a{};
   a.in0 = dev_rand((size_t)B * Sin * Sin * Cin, 1.f, 1);
@@ -148,10 +155,12 @@ int main(int argc, char** argv) {
   ConvArgs ap = a;  // the pipelined kernel takes the norm itself
   ap.ab = nullptr, ap.gn_stats0 = gstats, ap.gn_gamma = ggamma, ap.gn_beta = gbeta, ap.gn_nparts0 = gin.nparts, ap.gn_g = gin;
   if (hx2p && !conv_hx2p_supported(ap, mode)) { printf("hx2p: unsupported shape\n"); return 1; }
+  if (hx2q && !conv_hx2q_supported(ap, mode)) { printf("hx2q: unsupported shape\n"); return 1; }
   auto launch = [&]() {
     if (f32) launch_conv_mfma(a, mode, 0);
     else if (hx2) launch_conv_hx2(a, mode, 0);
     else if (hx2p) launch_conv_hx2p(ap, mode, 0);
+    else if (hx2q) launch_conv_hx2q(ap, mode, 0);
     else launch_conv_bx3(a, mode, 0);
   };
   {  // reference: the exact-fp32 MFMA kernel on the same data
@@ -182,6 +191,18 @@ int main(int argc, char** argv) {
     hipMemcpy(&fl, flag, 4, hipMemcpyDeviceToHost);
     printf("check vs f32 kernel: max|diff| %.3e (max|ref| %.3f), stats rel diff %.3e, range flag %u\n", emax, vmax, smax, fl);
   }
+#ifdef RGFM_HX2Q_SKEW
+  {
+    int sk[2] = {getenv("SKEW") ? atoi(getenv("SKEW")) : 0, getenv("SKEW_N") ? atoi(getenv("SKEW_N")) : 256};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_hx2q_skew), sk, sizeof(sk));
+  }
+#endif
+#ifdef RGFM_HX2Q_PROF
+  {
+    unsigned long long zq[16] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_hx2q_prof), zq, sizeof(zq));
+  }
+#endif
 #ifdef RGFM_HX2P_PROF
   unsigned long long zerop[34] = {0};
   hipMemcpyToSymbol(HIP_SYMBOL(g_hx2p_prof), zerop, sizeof(zerop));
@@ -204,8 +225,22 @@ int main(int argc, char** argv) {
   float ms;
   hipEventElapsedTime(&ms, e0, e1);
   const double us = ms * 1e3 / reps;
-  printf("%s S=%d Cin=%d Cout=%d mode=%d res=%d B=%d: %8.1f us  %6.1f TFLOP/s (fp32-equivalent)\n", f32 ? "f32" : (hx2 ? "hx2" : (hx2p ? "hx2p" : "bx3")), S, Cin,
+  printf("%s S=%d Cin=%d Cout=%d mode=%d res=%d B=%d: %8.1f us  %6.1f TFLOP/s (fp32-equivalent)\n", f32 ? "f32" : (hx2 ? "hx2" : (hx2p ? "hx2p" : (hx2q ? "hx2q" : "bx3"))), S, Cin,
          Cout, mode, res, B, us, flops / us / 1e6);
+#ifdef RGFM_HX2Q_PROF
+  if (hx2q) {
+    unsigned long long pq[16];
+    hipMemcpyFromSymbol(pq, HIP_SYMBOL(g_hx2q_prof), sizeof(pq));
+    const char* nm[7] = {"gn table", "decode", "barrier", "fill+acc", "barrier", "K loop", "epilogue"};
+    for (int g = 0; g < 2; ++g) {
+      printf("  wave %d (cycles per workgroup, s_memtime ticks):", g * 4);
+      double tot = 0;
+      for (int i = 0; i < 7; ++i) tot += (double)pq[g * 8 + i] / (double)pq[g * 8 + 7];
+      for (int i = 0; i < 7; ++i) printf(" %s %.0f |", nm[i], (double)pq[g * 8 + i] / (double)pq[g * 8 + 7]);
+      printf(" total %.0f\n", tot);
+    }
+  }
+#endif
 #ifdef RGFM_HX2P_PROF
   {
     unsigned long long pp[34];
