@@ -214,11 +214,14 @@ int conv_hx2p_init();
 void conv_hx2p_set_half(int v);  // launches with fewer workgroups than this are cut finer (0: never; the CU count)
 void conv_hx2p_set_w4(int v);  // tools/kbench A/B: 1 / 2 = four-wave workgroups forced, see conv_mfma_hx2p.hip
 void launch_conv_hx2p(const ConvArgs& a, int mode, hipStream_t s);
-// four-waves-per-SIMD version (conv_mfma_hx2q.hip: one tile x 64 channels per workgroup, two workgroups per CU) for
-// full launches over 16- / 32-pixel-wide rasters with Cout % 64 == 0; bit-identical results
+// four-waves-per-SIMD version (conv_mfma_hx2q.hip: one tile x 64 channels at a time, two workgroups per CU, several
+// tiles per workgroup behind one continuous staging stream) for full stride-1 launches over 16- / 32-pixel-wide
+// rasters with Cout % 64 == 0 and a consumer-side input norm; bit-identical results
 bool conv_hx2q_supported(const ConvArgs& a, int mode);
 int conv_hx2q_init();
 void conv_hx2q_set_min(int v);  // launches with fewer workgroups than this stay on conv_mfma_hx2p_kernel (0: never used)
+void conv_hx2q_set_target(int v);  // workgroups a launch is cut into when it has the tiles (two per CU)
+void conv_hx2q_set_tpw(int v);     // tools/kbench: force the tiles per workgroup
 void launch_conv_hx2q(const ConvArgs& a, int mode, hipStream_t s);
 // packs w (mode CONV_S1: [Cout][Cin][taps]; CONV_S2: the phase-major stride-2 order; CONV_T2: a ConvTranspose2d
 // weight [Cin][Cout][4][4], taps ignored) and writes the scale record hq[4] (device)

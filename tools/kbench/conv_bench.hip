@@ -66,6 +66,7 @@ int main(int argc, char** argv) {
   conv_hx2p_init();
   conv_hx2q_init();
   if (getenv("RGFM_HX2Q_MIN")) conv_hx2q_set_min(atoi(getenv("RGFM_HX2Q_MIN")));
+  if (getenv("RGFM_HX2Q_TPW")) conv_hx2q_set_tpw(atoi(getenv("RGFM_HX2Q_TPW")));
   if (getenv("RGFM_HX2P_W4")) conv_hx2p_set_w4(atoi(getenv("RGFM_HX2P_W4")));
   if (getenv("RGFM_HX2P_HALF")) conv_hx2p_set_half(atoi(getenv("RGFM_HX2P_HALF")));
 #if RGFM_HX2P_QEXP
@@ -191,12 +192,6 @@ int main(int argc, char** argv) {
     hipMemcpy(&fl, flag, 4, hipMemcpyDeviceToHost);
     printf("check vs f32 kernel: max|diff| %.3e (max|ref| %.3f), stats rel diff %.3e, range flag %u\n", emax, vmax, smax, fl);
   }
-#ifdef RGFM_HX2Q_SKEW
-  {
-    int sk[2] = {getenv("SKEW") ? atoi(getenv("SKEW")) : 0, getenv("SKEW_N") ? atoi(getenv("SKEW_N")) : 256};
-    hipMemcpyToSymbol(HIP_SYMBOL(g_hx2q_skew), sk, sizeof(sk));
-  }
-#endif
 #ifdef RGFM_HX2Q_PROF
   {
     unsigned long long zq[16] = {0};
@@ -231,13 +226,11 @@ int main(int argc, char** argv) {
   if (hx2q) {
     unsigned long long pq[16];
     hipMemcpyFromSymbol(pq, HIP_SYMBOL(g_hx2q_prof), sizeof(pq));
-    const char* nm[7] = {"gn table", "decode", "barrier", "fill+acc", "barrier", "K loop", "epilogue"};
+    const char* nm[7] = {"gn table", "decode+barrier", "fill", "acc init", "K loops", "epilogues", "whole workgroup"};
     for (int g = 0; g < 2; ++g) {
-      printf("  wave %d (cycles per workgroup, s_memtime ticks):", g * 4);
-      double tot = 0;
-      for (int i = 0; i < 7; ++i) tot += (double)pq[g * 8 + i] / (double)pq[g * 8 + 7];
+      printf("  wave %d (s_memtime ticks per workgroup, all its tiles):", g * 4);
       for (int i = 0; i < 7; ++i) printf(" %s %.0f |", nm[i], (double)pq[g * 8 + i] / (double)pq[g * 8 + 7]);
-      printf(" total %.0f\n", tot);
+      printf("\n");
     }
   }
 #endif
