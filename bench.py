@@ -44,6 +44,13 @@ import torch.distributed as dist  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_16BIT_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / f16 MFMA
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured with a float4 copy)
+ARITHMETIC = {
+    "hx2": "f32 emulated on the f16 matrix cores: operands as 2 scaled fp16 planes (22-bit significands), 3 of the 4 plane "
+           "products per fp32 product, fp32 accumulate; range-guarded with a split-bf16 fallback (DESIGN.md section 4)",
+    "bx3": "f32 emulated on the bf16 matrix cores: operands as 3 exact bf16 planes (24-bit significands), 6 products per "
+           "fp32 product, fp32 accumulate",
+    "f32": "f32 on the matrix cores: v_mfma_f32_32x32x2_f32",
+}
 PRODUCTS = {"hx2": 3, "bx3": 6}  # 16-bit MFMA products per fp32 multiply-add (conv_mfma_hx2*.hip, conv_mfma_bx3.hip)
 KCLASS = {"conv": 0, "other": 1, "conv_in<1>": 2, "conv_in<3>": 3, "conv_out<1>": 4, "conv_out<3>": 5,
           "guid_logp": 6, "guid_apply": 7}  # include/rgfm.h RGFM_KCLASS_*
@@ -103,8 +110,8 @@ def kernel_sources_sha():
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "ratio_guided_multimodal_fm_amd", "csrc")
-    for name in ("conv_hx2_common.h", "conv_mfma_hx2.hip", "conv_mfma_hx2p.hip", "conv_mfma_bx3.hip", "conv_mfma.hip",
-                 "rgfm_device.h", "rgfm_kernels.h"):
+    for name in ("conv_hx2_common.h", "conv_mfma_hx2.hip", "conv_mfma_hx2p.hip", "conv_mfma_hx2q.hip", "conv_mfma_bx3.hip",
+                 "conv_mfma.hip", "rgfm_device.h", "rgfm_kernels.h"):
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()
@@ -180,7 +187,16 @@ def main():
             if k >= 2:
                 hbm_classes[name] = _engine.profile_read(k)
         _engine.profile(enable=False)
+    ranks = None
     if world > 1:
+        # what every rank saw, gathered over RCCL: its rank, the world size of ITS process group, its device ordinal and its
+        # own time for the K calls -- the line then proves that N ranks on N devices ran
+        mine = torch.tensor([float(rank), float(dist.get_world_size()), float(torch.cuda.current_device()), elapsed],
+                            device=dev, dtype=torch.float64)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        ranks = [{"rank": int(v[0]), "world_size_seen": int(v[1]), "device": int(v[2]), "seconds": float(v[3])}
+                 for v in (t.cpu().tolist() for t in allr)]
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -192,20 +208,26 @@ def main():
         os.environ["RGFM_CONV"] = "f32"
         one_call(calls - 1)
         fence()
-        _engine.profile(enable=True, reset=True)
-        ta = time.perf_counter()
-        one_call(calls - 1)
-        fence()
-        alt_elapsed = time.perf_counter() - ta
-        a_ms, _, a_n, a_fl = _engine.profile_read(0)
-        _engine.profile(enable=False)
+        runs = []
+        for _ in range(3):
+            _engine.profile(enable=True, reset=True)
+            ta = time.perf_counter()
+            one_call(calls - 1)
+            fence()
+            el = time.perf_counter() - ta
+            a_ms, _, a_n, a_fl = _engine.profile_read(0)
+            _engine.profile(enable=False)
+            runs.append((el, a_ms, a_fl))
+        runs.sort()
+        alt_elapsed, a_ms, a_fl = runs[1]  # the median call
         if conv_mode_env is None:
             os.environ.pop("RGFM_CONV", None)
         else:
             os.environ["RGFM_CONV"] = conv_mode_env
         ach_a = a_fl / (a_ms * 1e-3) / 1e12
         alt = {"conv": "v_mfma_f32_32x32x2_f32 (RGFM_CONV=f32)", "value": B / alt_elapsed, "unit": "paired images/sec",
-               "achieved": ach_a, "peak": PEAK_FP32_MFMA_TFLOPS, "frac": ach_a / PEAK_FP32_MFMA_TFLOPS, "calls": 1}
+               "achieved": ach_a, "peak": PEAK_FP32_MFMA_TFLOPS, "frac": ach_a / PEAK_FP32_MFMA_TFLOPS, "calls": 3,
+               "statistic": "median call"}
 
     arith = None
     gpath = os.path.join(ROOT, "tests", "golden", "fp64_eval.npz")
@@ -239,8 +261,8 @@ def main():
         import ctypes
         L = _lib.lib()
         tf, gb = ctypes.c_double(), ctypes.c_double()
+        _lib.check(L.rgfm_ubench_hbm_copy(1 << 30, ctypes.byref(gb)))  # (the copy first: the MFMA loop leaves the chip hot)
         _lib.check(L.rgfm_ubench_mfma_f16(ctypes.byref(tf)))
-        _lib.check(L.rgfm_ubench_hbm_copy(1 << 30, ctypes.byref(gb)))
         ceilings = {"mfma_f16_tflops": tf.value, "hbm_copy_gbs": gb.value}
 
     if rank == 0:
@@ -257,7 +279,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",  # fp32 tensors and accumulation end to end; see roofline.conv_arithmetic
+            "dtype": "f32",  # fp32 tensors and accumulation end to end; how the conv products are formed: "arithmetic"
+            "arithmetic": ARITHMETIC.get(conv_mode, conv_mode),
+            "range_fallbacks": _engine.range_fallbacks,  # calls repeated on the split-bf16 convs by the fp16 range guard (0: none)
             "data": "synthetic",
             "config": {
                 "workload": "MNIST32 (1x32x32) + SVHN (3x32x32) pair, mc_feng guidance "
@@ -292,7 +316,7 @@ def main():
             # committed under profiles/ with the hash of the kernel sources it was taken with; it is reported only
             # while those sources are unchanged, and the line names the file and its sha256.
             traffic, traffic_src = None, None
-            tpath = os.path.join(ROOT, "profiles", f"r02_conv_traffic_{conv_mode}.json")
+            tpath = os.path.join(ROOT, "profiles", f"r03_conv_traffic_{conv_mode}.json")
             if os.path.exists(tpath) and args.batch_per_gpu == 512:
                 import hashlib
                 with open(tpath, "rb") as f:
@@ -316,7 +340,7 @@ def main():
                           "launches overlap; sum_launch_ms double-counts that time; RGFM_OVERLAP=0 serialises)",
                 "kernel_time_share": conv_ms * 1e-3 / elapsed,
             }
-            lt = os.path.join(ROOT, "profiles", "r02_bench_layers_serial.txt")
+            lt = os.path.join(ROOT, "profiles", "r03_bench_layers_serial.txt")
             if os.path.exists(lt) and conv_mode == "hx2":
                 # (static pointer, not a live number) rocprofv3 per-layer table of one main-loop step with every layer's
                 # own roofline max(MFMA ceiling, HBM copy rate): a third of the step is memory-bound, DESIGN.md 4
@@ -343,6 +367,8 @@ def main():
                 line["roofline"]["exact_fp32_mode"] = alt
             if arith is not None:
                 line["roofline"]["arithmetic_check"] = arith
+        if ranks is not None:
+            line["ranks"] = ranks
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)

@@ -21,16 +21,20 @@
  *     thrown across the ABI; rgfm_last_error() returns text for the calling
  *     thread's last failure;
  *   - one host thread per handle; distinct handles are independent;
- *   - arithmetic: fp32 tensors, fp32 accumulation.  By default the 3x3 / transposed
- *     convolutions form each fp32 product from a two-way fp16 split of both (power-of-two
- *     scaled) operands on the f16 matrix cores: three products, fp32 accumulate, per-product
- *     error <= 3 * 2^-24 relative, measured error against float64 equal to the fp32
- *     matrix-core path.  That path needs |activation| < 2048 and
- *     finite weights with max|w| in [2^-40, 2^40] per conv; convs outside the weight range
- *     are routed to the bf16 path at create time, and an activation outside the range raises
- *     a device flag (rgfm_range_flag_read) on which the caller repeats the call with
- *     RGFM_CONV=bx3.  RGFM_CONV=bx3: exact three-way bf16 split, six products, fp32 range.
- *     RGFM_CONV=f32: v_mfma_f32_32x32x2_f32 for every convolution.
+ *   - arithmetic: fp32 tensors, fp32 accumulation.  By default (RGFM_CONV_HX2) the 3x3 /
+ *     transposed convolutions EMULATE each fp32 product on the f16 matrix cores: both
+ *     (power-of-two scaled) operands are held as two fp16 planes -- 22 significant bits -- and
+ *     three of the four plane products are accumulated in fp32 (product
+ *     error measured 2^-24.8 median, 2^-20.3 at the 99.9th percentile; one whole U-Net
+ *     evaluation against float64: 2.6e-6, the reference's own fp32 run 1.7e-6).  The
+ *     representation has a window: activations 2^-8 <= max|a| per wave block and |a| < 2048,
+ *     GroupNorm parameters and weights of ordinary magnitude.  Convs whose weights or norm
+ *     parameters are outside it are routed to the split-bf16 kernel when the handle is
+ *     created; activations outside it raise the handle's range flag (rgfm_unet_range_flag:
+ *     bit 0 too large, bit 1 too small), on which the caller repeats the call with the handle
+ *     set to RGFM_CONV_BX3 / RGFM_CONV_F32 (rgfm_unet_set_conv_mode) -- the Python host does both.
+ *     RGFM_CONV_BX3: exact three-way bf16 split, six products, fp32 exponent range.
+ *     RGFM_CONV_F32: v_mfma_f32_32x32x2_f32 for every convolution.
  */
 #ifndef RGFM_H_
 #define RGFM_H_
@@ -42,7 +46,7 @@
 extern "C" {
 #endif
 
-#define RGFM_ABI_VERSION 2
+#define RGFM_ABI_VERSION 3
 
 #define RGFM_OK 0
 #define RGFM_EINVAL (-1)    /* bad argument / unsupported shape          */
@@ -273,11 +277,25 @@ int rgfm_profile_reserve(int64_t launches);
 int rgfm_ubench_mfma_f16(double* tflops);
 int rgfm_ubench_hbm_copy(size_t bytes, double* gbps);
 
-/* Range flag of the default fp16 conv path (see "arithmetic" above): waits for `stream`, then
- * *flagged = 1 if any convolution launched on the current device since the last reset staged an
- * activation outside the fp16 range -- the outputs of those calls must be recomputed with
- * RGFM_CONV=bx3 (the Python host does this automatically).  reset != 0 clears the flag. */
-int rgfm_range_flag_read(int* flagged, int reset, rgfm_stream_t stream);
+/* Conv arithmetic of ONE handle (see "arithmetic" above); RGFM_CONV_DEFAULT follows the RGFM_CONV environment
+ * variable (hx2 | bx3 | f32, read once per API call; unset = hx2).  A handle setting, not process state: two host
+ * threads driving two handles never change each other's arithmetic. */
+#define RGFM_CONV_DEFAULT (-1)
+#define RGFM_CONV_HX2 0
+#define RGFM_CONV_BX3 1
+#define RGFM_CONV_F32 2
+int rgfm_unet_set_conv_mode(rgfm_unet* h, int mode);
+int rgfm_fmnet_set_conv_mode(rgfm_fmnet* h, int mode);
+
+/* Range flag of the default fp16 conv path, one word per handle: waits for `stream`, then *flagged = the bits raised
+ * by the handle's launches since the last reset -- 1: a staged activation reached |a| >= 2048 (fp16 overflow);
+ * 2: an output that a later conv stages without a GroupNorm in front (the residual stream: reference
+ * src/models/unet_flexible.py:85,96,107-108 consume it in fp32 at any magnitude) had a 64-pixel wave block whose
+ * largest |value| was below 2^-8, where the two fp16 planes lose bits.  Non-zero: the results of those calls are not
+ * fp32-class; repeat them with rgfm_*_set_conv_mode(h, RGFM_CONV_BX3) (bit 0) or RGFM_CONV_F32 (bit 1: the exact fp32
+ * convs are the reference's arithmetic at any magnitude).  reset != 0 clears the word. */
+int rgfm_unet_range_flag(rgfm_unet* h, int* flagged, int reset, rgfm_stream_t stream);
+int rgfm_fmnet_range_flag(rgfm_fmnet* h, int* flagged, int reset, rgfm_stream_t stream);
 
 int rgfm_abi_version(void);
 const char* rgfm_last_error(void);

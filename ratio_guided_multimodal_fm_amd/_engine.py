@@ -75,42 +75,55 @@ def engine_property(factory):
 
 
 # ---- range guard of the default fp16 conv path -------------------------------------------------
-# conv_mfma_hx2.hip needs |activation| < 2048; outside that it raises a device flag instead of
-# returning wrong numbers silently.  Every public compute entry point below runs under
-# _range_guarded: if the flag is up after the call, the in-place state is restored and the call is
-# repeated with RGFM_CONV=bx3 (split-bf16 convs, fp32 range).  RGFM_RANGE_CHECK=0 disables the
-# check (and its end-of-call synchronisation), e.g. for stream capture.
+# The fp16 two-plane convs (conv_mfma_hx2*.hip) emulate fp32 products inside a window: activations
+# below 2048, and residual-stream tensors (consumed without a GroupNorm in front) not smaller than
+# 2^-8 per 64-pixel block.  Outside it a launch raises the range flag of ITS HANDLE instead of
+# returning degraded numbers.  Every public compute entry point below runs under _range_guarded:
+# if a flag of one of the engines involved is up after the call, the in-place state is restored
+# and the call is repeated with those handles switched to the split-bf16 convs (too large: fp32 exponent
+# range) or the exact fp32 matrix-core convs (too small) -- rgfm_*_set_conv_mode, a handle setting,
+# nothing process-wide is touched.  RGFM_RANGE_CHECK=0
+# disables the check (and its end-of-call synchronisation), e.g. for stream capture.
+CONV_DEFAULT, CONV_HX2, CONV_BX3, CONV_F32 = -1, 0, 1, 2
+
 
 def _hx2_active():
     return os.environ.get("RGFM_CONV", "hx2") == "hx2" and os.environ.get("RGFM_RANGE_CHECK", "1") != "0"
 
 
 range_fallbacks = 0  # number of calls repeated on the bf16 path (tests read it)
+last_range_flags = 0  # OR of the flag bits that caused the latest fallback (1: too large, 2: too small)
 
 
-def _range_guarded(device, state, fn):
-    """fn() with the fp16-range check; `state` = tensors fn updates in place."""
-    global range_fallbacks
-    if not _hx2_active():
+def _range_guarded(device, state, fn, engines):
+    """fn() with the fp16-range check; `state` = tensors fn updates in place, `engines` = the
+    velocity-net engines whose handles fn launches on."""
+    global range_fallbacks, last_range_flags
+    engines = [e for i, e in enumerate(engines) if e is not None and all(e is not o for o in engines[:i])]
+    if not _hx2_active() or not engines:
         return fn()
     saved = [t.clone() for t in state]
     out = fn()
-    flag = ctypes.c_int()
+    bits = 0
     with torch.cuda.device(device):
-        _lib.check(_lib.lib().rgfm_range_flag_read(ctypes.byref(flag), 1, _stream(device)))
-    if flag.value:
+        for e in engines:
+            bits |= e.read_range_flag(device)
+    if bits:
         range_fallbacks += 1
+        last_range_flags = bits
         for t, t0 in zip(state, saved):
             t.copy_(t0)
-        prev = os.environ.get("RGFM_CONV")
-        os.environ["RGFM_CONV"] = "bx3"
-        try:
-            out = fn()
-        finally:
-            if prev is None:
-                del os.environ["RGFM_CONV"]
-            else:
-                os.environ["RGFM_CONV"] = prev
+        # too large (bit 0): the split-bf16 convs have fp32's exponent range at the top; too small (bit 1): the repeat
+        # runs on the exact fp32 matrix-core convs, which ARE the reference's arithmetic at any magnitude
+        fallback = CONV_F32 if bits & 2 else CONV_BX3
+        with torch.cuda.device(device):
+            for e in engines:
+                e.set_conv_mode(device, fallback)
+            try:
+                out = fn()
+            finally:
+                for e in engines:
+                    e.set_conv_mode(device, CONV_DEFAULT)
     return out
 
 
@@ -198,6 +211,16 @@ class _VelocityEngine(_EngineBase):
         _lib.check(getattr(L, fn_name)(self.handle(device), int(batch), ctypes.byref(n)))
         return self._ws.get(n.value, device), n.value
 
+    def read_range_flag(self, device, reset=True):
+        """Flag bits raised by this engine's launches since the last reset (waits for the current stream)."""
+        flag = ctypes.c_int()
+        _lib.check(self._fn("range_flag")(self.handle(device), ctypes.byref(flag), 1 if reset else 0, _stream(device)))
+        return flag.value
+
+    def set_conv_mode(self, device, mode):
+        """Conv arithmetic of this engine's handle: CONV_DEFAULT (RGFM_CONV), CONV_HX2, CONV_BX3, CONV_F32."""
+        _lib.check(self._fn("set_conv_mode")(self.handle(device), int(mode)))
+
     def forward(self, x, t):
         m = self._module()
         self._check_eval(m)
@@ -221,7 +244,7 @@ class _VelocityEngine(_EngineBase):
                 _lib.check(self._fn("forward")(h, _ptr(x), _ptr(t), t.numel(), _ptr(out), B, _ptr(ws), nb,
                                                _stream(dev)))
             return out
-        return _range_guarded(dev, [], run)
+        return _range_guarded(dev, [], run, [self])
 
 
 class FmNetEngine(_VelocityEngine):
@@ -372,6 +395,9 @@ class RatioEngine(_EngineBase):
             raise _lib.RgfmError("the log-ratio gradient is implemented for RatioEstimatorMNISTSVHN only")
         if x.shape[0] != y.shape[0]:
             raise _lib.RgfmError("x and y must have the same batch size")
+        if x.dim() != 4 or y.dim() != 4 or tuple(x.shape[1:]) != (1, 32, 32) or tuple(y.shape[1:]) != (3, 32, 32):
+            raise _lib.RgfmError("expected x of shape [B,1,32,32] and y of shape [B,3,32,32], got "
+                                 f"{tuple(x.shape)} and {tuple(y.shape)}")
         n = x.shape[0]
         x, y = x.contiguous(), y.contiguous()
         gx, gy = torch.empty_like(x), torch.empty_like(y)
@@ -398,7 +424,8 @@ _sampler_ws = _Workspace()
 def sample_single(model, x, num_steps, step_begin=0, step_end=None):
     """In-place unguided Euler integration of `x` (rgfm_sample_single)."""
     if x.is_cuda and x.shape[0]:
-        return _range_guarded(x.device, [x], lambda: _sample_single(model, x, num_steps, step_begin, step_end))
+        return _range_guarded(x.device, [x], lambda: _sample_single(model, x, num_steps, step_begin, step_end),
+                              [model._engine])
     return _sample_single(model, x, num_steps, step_begin, step_end)
 
 
@@ -450,7 +477,7 @@ def sample_two_streams(fm_x, x, fm_y, y, num_steps):
         cur.wait_stream(side)
         return x, y
     if x.is_cuda and y.is_cuda:
-        return _range_guarded(dev, [x, y], run)
+        return _range_guarded(dev, [x, y], run, [fm_x._engine, fm_y._engine])
     return run()
 
 
@@ -488,7 +515,7 @@ def sample_pair(fm_x, fm_y, x, y, mc_x1, mc_y1, mc_ratios, num_steps, gamma, ste
                                           float(gamma), int(step_begin), int(step_end), _ptr(ws),
                                           nb.value, _stream(dev)))
         return x, y
-    return _range_guarded(dev, [x, y], run)
+    return _range_guarded(dev, [x, y], run, [fm_x._engine, fm_y._engine])
 
 
 def sample_pair_grad(fm_x, fm_y, ratio_estimator, x, y, num_steps, gamma, step_begin=0, step_end=None):
@@ -518,7 +545,7 @@ def sample_pair_grad(fm_x, fm_y, ratio_estimator, x, y, num_steps, gamma, step_b
             _lib.check(L.rgfm_sample_pair_grad(hx, hy, hr, _ptr(x), _ptr(y), B, int(num_steps), float(gamma),
                                                int(step_begin), int(step_end), _ptr(ws), nb.value, _stream(dev)))
         return x, y
-    return _range_guarded(dev, [x, y], run)
+    return _range_guarded(dev, [x, y], run, [fm_x._engine, fm_y._engine])
 
 
 def guidance_apply(x, y, vx, vy, mc_x1, mc_y1, mc_ratios, t, gamma, want_weights=False):

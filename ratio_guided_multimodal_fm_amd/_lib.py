@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RGFM_LIB: another build of the same ABI (A/B measurements of two library versions inside one run)
 LIB_PATH = os.environ.get("RGFM_LIB") or os.path.join(_HERE, "csrc", "librgfm_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 
@@ -86,7 +86,10 @@ SIGNATURES = {
     "rgfm_profile_reserve": (c_int, [c_int64]),
     "rgfm_ubench_mfma_f16": (c_int, [P(c_double)]),
     "rgfm_ubench_hbm_copy": (c_int, [c_size_t, P(c_double)]),
-    "rgfm_range_flag_read": (c_int, [P(c_int), c_int, c_void_p]),
+    "rgfm_unet_set_conv_mode": (c_int, [c_void_p, c_int]),
+    "rgfm_fmnet_set_conv_mode": (c_int, [c_void_p, c_int]),
+    "rgfm_unet_range_flag": (c_int, [c_void_p, P(c_int), c_int, c_void_p]),
+    "rgfm_fmnet_range_flag": (c_int, [c_void_p, P(c_int), c_int, c_void_p]),
     "rgfm_abi_version": (c_int, []),
     "rgfm_last_error": (ctypes.c_char_p, []),
 }

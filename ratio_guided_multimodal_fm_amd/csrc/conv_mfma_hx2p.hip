@@ -888,6 +888,17 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, (RGFM_HX2P_QEXP
       }
       if (a.fin_ab && sample_ok) fin_arrive(a, bw, lane_e, nparts, MODE == CONV_T2);
     }
+    if (a.small_check && a.range_flag) {  // (ConvArgs::small_check: the output's low range)
+      float m = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (FULL || (vmask[mt] & (1u << r))) m = fmaxf(m, fabsf(acc[mt][nt][r]));
+      hx_small_flag(a.range_flag, m);
+    }
   };
   const bool full_seg = sample_ok && ((g.spt == 1) ? (nvalid - 64 * seg >= 64) : (HW == 64));  // wave-uniform
   if (full_seg) epilogue(std::true_type{});

@@ -26,11 +26,14 @@
 namespace rgfm {
 
 #ifndef RGFM_HX2Q_STAGGER
-#define RGFM_HX2Q_STAGGER 0  // 1: waves 4-7 transform + store their halo items AFTER the unit's MFMAs (waves 0-3: before)
+#define RGFM_HX2Q_STAGGER 1  // 1: waves 4-7 transform + store their halo items AFTER the unit's MFMAs (waves 0-3: before)
 #endif
 #ifndef RGFM_HX2Q_ABL
 #define RGFM_HX2Q_ABL 0      // kbench timing ablations (results wrong): 1 no halo staging in the K loop, 2 nor weight DMA,
 #endif                       // 3 nor fragment reads (MFMAs + barriers only), 4: everything but the MFMAs
+#ifndef RGFM_HX2Q_MIX
+#define RGFM_HX2Q_MIX 0      // 1: the early half's staging interleaved with the unit's MFMAs by sched_group_barrier (one stream)
+#endif
 #ifndef RGFM_HX2Q_PRIO
 #define RGFM_HX2Q_PRIO 0     // 1: raised issue priority during a unit's MFMAs
 #endif
@@ -363,12 +366,25 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_hx2q_kernel(const ConvArgs a
     __builtin_amdgcn_s_setprio(0);
 #endif
   };
+  // RGFM_HX2Q_MIX: ask the scheduler for NM groups of {1 MFMA, 1 LDS read, NV vector-ALU instructions}
+#define HX2Q_MIX_PATTERN(NM, NV)                                   \
+  do {                                                             \
+    _Pragma("unroll") for (int i_ = 0; i_ < (NM); ++i_) {          \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           \
+      __builtin_amdgcn_sched_group_barrier(0x002, (NV), 0);        \
+    }                                                              \
+  } while (0)
   // the weight half of a unit's staging: the next unit's weights -> the other weight buffer (free since the last barrier)
+#if RGFM_HX2Q_MIX
+#define HX2Q_W_STEP() wdma(u1, gu + 1)
+#else
 #define HX2Q_W_STEP()                       \
   do {                                      \
     wdma(u1, gu + 1);                       \
     __builtin_amdgcn_sched_barrier(0);      \
   } while (0)
+#endif
   // end of a unit: this wave's DMA pieces have landed (N: the halo fetches issued behind them stay in flight), barrier
 #define HX2Q_U_NEXT(N)                      \
   do {                                      \
@@ -445,8 +461,13 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_hx2q_kernel(const ConvArgs a
         commit_a(xf_tag, p1, gc + 1, 0);
         HX2Q_W_STEP();
         issue_a(p2, 0);
+#if RGFM_HX2Q_MIX
+        taps3(0);
+        HX2Q_MIX_PATTERN(18, 2);
+#else
         __builtin_amdgcn_sched_barrier(0);
         taps3(0);
+#endif
       } else {
         HX2Q_W_STEP();
         taps3(0);
@@ -462,8 +483,13 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_hx2q_kernel(const ConvArgs a
         HX2Q_W_STEP();
         issue_a(p2, 1);
         issue_a(p2, 2);
+#if RGFM_HX2Q_MIX
+        taps3(1);
+        HX2Q_MIX_PATTERN(18, 4);
+#else
         __builtin_amdgcn_sched_barrier(0);
         taps3(1);
+#endif
       } else {
         HX2Q_W_STEP();
         taps3(1);
@@ -547,6 +573,14 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_hx2q_kernel(const ConvArgs a
       if (hp_e == 0) store_stats(ke, ke.stats_out + (((size_t)tb * nparts + part) * ke.Cout + ch_e) * 2, mean, m2);
       if (ke.fin_ab) fin_arrive(ke, tb, lane_e, nparts, false);
     }
+    if (ke.small_check && ke.range_flag) {  // (ConvArgs::small_check: the output's low range)
+      float m = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(acc[mt][r]));
+      hx_small_flag(ke.range_flag, m);
+    }
     QPROF_T(tt3);
     QPROF_ACC(0, tt0, tt1);
     QPROF_ACC(1, tt1, tt2);
@@ -586,6 +620,8 @@ static int g_hx2q_min = 256;
 void conv_hx2q_set_min(int v) { g_hx2q_min = v; }
 static int g_hx2q_target = 512;  // workgroups a launch is cut into when it has the tiles: two per CU
 void conv_hx2q_set_target(int v) { g_hx2q_target = v > 0 ? v : 1; }
+static int g_hx2q_all = 0;       // tools/kbench: every supported shape, not only those where this kernel is the faster one
+void conv_hx2q_set_all(int v) { g_hx2q_all = v; }
 static int g_hx2q_tpw = 0;       // tools/kbench: force the tiles per workgroup (0: hx2q_tiles_per_wg)
 void conv_hx2q_set_tpw(int v) { g_hx2q_tpw = v; }
 
@@ -618,7 +654,12 @@ bool conv_hx2q_supported(const ConvArgs& a, int mode) {
   if (a.Cout % 64 != 0 || (a.C0 + a.C1) % KC != 0) return false;
   if (a.res_mode == 2 && (a.R0 + a.R1) % KC != 0) return false;
   if (hx2q_lds_bytes(a, hx2q_tiles_per_wg(a)) > 80 * 1024) return false;
-  return geom_num_tiles(g, a.B) * (a.Cout / 64) >= g_hx2q_min;
+  if (geom_num_tiles(g, a.B) * (a.Cout / 64) < g_hx2q_min) return false;
+  // Where it pays (tools/kbench, same box, B = 512): 64 -> 64 at 32x32 +9..10 %, 128 -> 64 +1 %; with a fused 1x1 skip
+  // (192 -> 64: -1.5 %), at 16x16 (-3 %) and with Cout = 128 (two workgroups per tile transform the halo twice:
+  // -3..-8 %) conv_mfma_hx2p_kernel is faster.  g_hx2q_all (kbench) lifts the restriction.
+  if (g_hx2q_all) return true;
+  return g.W == 32 && a.Cout == 64 && a.C0 + a.C1 <= 128 && a.res_mode != 2;
 }
 
 int conv_hx2q_init() {

@@ -240,7 +240,7 @@ struct Modes {
   bool graph = false;     // RGFM_GRAPH=1: the guided steps of the paired U-Net loop replayed from one captured hipGraph
                           // (bit-identical; measured 0.995-1.002x of the kernel-by-kernel path: the host is not the bottleneck)
 };
-Modes g_modes;
+thread_local Modes g_modes;  // per host thread: a handle's own conv arithmetic (rgfm_*_set_conv_mode) overrides it per network walk
 void refresh_modes() {
   Modes m;
   const char* e = getenv("RGFM_CONV");
@@ -261,6 +261,16 @@ void refresh_modes() {
   g_modes = m;
 }
 
+// A handle's own conv arithmetic (rgfm_unet_set_conv_mode / rgfm_fmnet_set_conv_mode; -1: the environment's) for the
+// duration of one network walk.
+struct ModeScope {
+  int saved;
+  explicit ModeScope(int handle_mode) : saved(g_modes.conv) {
+    if (handle_mode >= 0) g_modes.conv = handle_mode;
+  }
+  ~ModeScope() { g_modes.conv = saved; }
+};
+
 // Per-device state, created by the first rgfm_*_create on that device (never inside forward / sample calls):
 // raised dynamic-LDS limits (a per-device function attribute), the side stream + fork/join events of the paired
 // sampler, and the range-flag word of conv_mfma_hx2.hip.
@@ -274,7 +284,6 @@ struct DevState {
   // forked from / joined back into the default stream with these events
   hipStream_t main = nullptr;
   hipEvent_t main_fork = nullptr, main_join = nullptr;
-  unsigned* range_flag = nullptr;
   // hipGraphs of earlier sampler calls that may still be executing: destroyed once `graph_done` (recorded behind the
   // latest replay) has completed
   hipEvent_t graph_done = nullptr;
@@ -307,8 +316,6 @@ int ensure_init() {
     HIP_TRY(hipStreamCreateWithFlags(&d.main, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&d.main_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&d.main_join, hipEventDisableTiming));
-    HIP_TRY(hipMalloc(&d.range_flag, 256));
-    HIP_TRY(hipMemset(d.range_flag, 0, 256));
     d.init = true;
   }
   return RGFM_OK;
@@ -325,20 +332,29 @@ void launch_conv(const ConvArgs& c, int mode, hipStream_t s) {
 }  // namespace
 
 // ------------------------------------------------------------------ fp16-path range flag
-// conv_mfma_hx2.hip ORs 1 into the device's flag word when it stages an activation with |S_A a| >= 32768 (fp16
-// would overflow): the results of every call since the last reset are then unusable and the caller repeats them
-// with RGFM_CONV=bx3 (fp32 range).  Synchronises `stream`.
-extern "C" int rgfm_range_flag_read(int* flagged, int reset, rgfm_stream_t stream) {
+// Every U-Net / FlowMatchingModel handle owns one device word.  conv_mfma_hx2*.hip OR into it: bit 0 when a staged
+// activation reaches |S_A a| >= 32768 (fp16 would overflow), bit 1 when an output that a later conv stages raw is too
+// small for the two-plane representation (ConvArgs::small_check).  Either way the results of the handle's calls since
+// the last reset are not fp32-class and the caller repeats them with the handle switched to RGFM_CONV_BX3 (fp32
+// range).  Per handle, so that two threads / two engines on one device cannot consume each other's flag.
+static int read_flag_word(unsigned* word, int* flagged, int reset, hipStream_t s) {
   if (!flagged) return fail(RGFM_EINVAL, "null output");
-  DevState* ds = cur_dev();
   *flagged = 0;
-  if (!ds) return RGFM_OK;  // nothing has run on this device
-  hipStream_t s = (hipStream_t)stream;
+  if (!word) return RGFM_OK;
   unsigned v = 0;
-  HIP_TRY(hipMemcpyAsync(&v, ds->range_flag, sizeof(v), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(&v, word, sizeof(v), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  *flagged = v ? 1 : 0;
-  if (reset && v) HIP_TRY(hipMemsetAsync(ds->range_flag, 0, sizeof(v), s));
+  *flagged = (int)v;
+  if (reset && v) HIP_TRY(hipMemsetAsync(word, 0, sizeof(v), s));
+  return RGFM_OK;
+}
+static int alloc_flag_word(unsigned** word) {
+  HIP_TRY(hipMalloc(word, 256));
+  HIP_TRY(hipMemset(*word, 0, 256));
+  return RGFM_OK;
+}
+static int check_conv_mode(int mode) {
+  if (mode < -1 || mode > CONV_ARITH_F32) return fail(RGFM_EINVAL, "conv mode must be RGFM_CONV_DEFAULT, _HX2, _BX3 or _F32");
   return RGFM_OK;
 }
 
@@ -351,7 +367,8 @@ struct rgfm_unet {
   size_t n_packedh = 0;
   float* hq = nullptr;      // [n_hq][4] scale records of packedh
   int n_hq = 0;
-  unsigned* range_flag = nullptr;  // the device's range-flag word (DevState)
+  unsigned* range_flag = nullptr;  // this handle's range-flag word
+  int conv_mode = -1;              // rgfm_unet_set_conv_mode: -1 = RGFM_CONV from the environment
   unsigned short* packed3 = nullptr;  // 3-plane bf16 weights (conv_mfma_bx3.hip)
   size_t n_packed3 = 0;
   float* freqs = nullptr;
@@ -591,8 +608,9 @@ struct UNetRun {
     return ab;
   }
   // generic 3x3 conv launch
+  // raw_consumed: a later conv stages this output without a GroupNorm in front (ConvArgs::small_check)
   Tensor conv(const Tensor& a, const Tensor* b, const NormRef* norm, const ConvW& w, int mode, const float* temb,
-              int res_mode, const Tensor* r0, const Tensor* r1, const ConvW* sk) {
+              int res_mode, const Tensor* r0, const Tensor* r1, const ConvW* sk, bool raw_consumed) {
     const int So = mode == CONV_S2 ? a.S / 2 : (mode == CONV_UP2 ? a.S * 2 : a.S);
     Tensor o = new_tensor(w.cout, So);
     float* ab_buf = norm ? ws->f((size_t)B * (a.C + (b ? b->C : 0)) * 2) : nullptr;  // used by the table path only
@@ -620,6 +638,7 @@ struct UNetRun {
     c.halo_px = mode == CONV_S2 ? c.g.spt * (2 * c.g.th + 1) * (2 * c.g.W + 1) : c.g.spt * (c.g.th + 2) * (c.g.W + 2);
     const int kprod = 9 * w.cin + (res_mode == 2 ? sk->cin : 0);
     fill_hx2(c, h->packedh, h->hq, h->range_flag, w, res_mode == 2 ? sk : nullptr);
+    if (g_modes.conv == CONV_ARITH_HX2) c.range_flag = h->range_flag, c.small_check = raw_consumed ? 1 : 0;
     if (norm) {
       const TileGeom gg = make_geom(a.S, a.S);
       if (!try_consumer_gn(c, mode, a.stats, b ? b->stats : nullptr, gg.nparts, gg, h->params + norm->gamma,
@@ -634,9 +653,10 @@ struct UNetRun {
   // ResBlock.forward (unet_flexible.py:71-85)
   Tensor resblock(const ResW& r, const Tensor& a, const Tensor* b) {
     const NormRef n1{r.n1w, r.n1b}, n2{r.n2w, r.n2b};
-    Tensor h1 = conv(a, b, &n1, r.c1, CONV_S1, dry ? nullptr : temb_row + r.temb_off, 0, nullptr, nullptr, nullptr);
+    Tensor h1 = conv(a, b, &n1, r.c1, CONV_S1, dry ? nullptr : temb_row + r.temb_off, 0, nullptr, nullptr, nullptr, false);
     record(h1);
-    Tensor o = conv(h1, nullptr, &n2, r.c2, CONV_S1, nullptr, r.has_skip ? 2 : 1, &a, b, r.has_skip ? &r.sk : nullptr);
+    // (a ResBlock's output is the residual stream: the next block's 1x1 skip, a Downsample or an Upsample reads it raw)
+    Tensor o = conv(h1, nullptr, &n2, r.c2, CONV_S1, nullptr, r.has_skip ? 2 : 1, &a, b, r.has_skip ? &r.sk : nullptr, true);
     record(o);
     return o;
   }
@@ -645,6 +665,7 @@ struct UNetRun {
   // may be non-null... both allowed: v_out receives the velocity, x_state the Euler update.
   int run(const float* x, float* v_out, float* x_state, float dt) {
     const rgfm_unet_desc& d = h->d;
+    ModeScope mode_scope(h->conv_mode);
     if (!dry && h->trace) h->acts.clear();
     int S = d.img_size;
     Tensor cur = new_tensor(h->mc, S);
@@ -652,6 +673,7 @@ struct UNetRun {
       ConvInArgs ci{};
       ci.x = x, ci.w = h->params + h->icw, ci.bias = h->params + h->icb;
       ci.out = cur.data, ci.stats_out = cur.stats, ci.B = B, ci.C0 = h->mc, ci.g = make_geom(S, S);
+      ci.range_flag = h->range_flag, ci.small_check = g_modes.conv == CONV_ARITH_HX2 ? 1 : 0;  // (the last decoder block's skip reads it raw)
       // algorithmic bytes: the NCHW image in, the NHWC map (+ its statistics) out
       const TileGeom g0 = make_geom(S, S);
       ProfScope p(d.in_channels == 1 ? RGFM_KCLASS_CONV_IN1 : RGFM_KCLASS_CONV_IN3,
@@ -667,7 +689,7 @@ struct UNetRun {
         skips.push_back(cur);
       }
       if (l < d.num_levels - 1) {
-        cur = conv(cur, nullptr, nullptr, h->down[l], CONV_S2, nullptr, 0, nullptr, nullptr, nullptr);
+        cur = conv(cur, nullptr, nullptr, h->down[l], CONV_S2, nullptr, 0, nullptr, nullptr, nullptr, true);
         record(cur);
         skips.push_back(cur);
       }
@@ -682,7 +704,7 @@ struct UNetRun {
         cur = resblock(h->dec[di++], cur, &sk);
       }
       if (l > 0) {
-        cur = conv(cur, nullptr, nullptr, h->up[ui++], CONV_UP2, nullptr, 0, nullptr, nullptr, nullptr);
+        cur = conv(cur, nullptr, nullptr, h->up[ui++], CONV_UP2, nullptr, 0, nullptr, nullptr, nullptr, true);
         record(cur);
       }
     }
@@ -766,7 +788,7 @@ extern "C" int rgfm_unet_create(const rgfm_unet_desc* desc, const float* params_
   if (hipMalloc(&h->packed, (h->n_packed + 4) * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(packed)");
   if (hipMalloc(&h->packedh, (h->n_packedh + 8) * sizeof(unsigned short)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(packedh)");
   if (hipMalloc(&h->hq, ((size_t)h->n_hq * 4 + 4) * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(hq)");
-  h->range_flag = cur_dev()->range_flag;
+  if (alloc_flag_word(&h->range_flag) != RGFM_OK) return bail(RGFM_ENOMEM, "hipMalloc(range flag)");
   if (hipMalloc(&h->packed3, (h->n_packed3 + 8) * sizeof(unsigned short)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(packed3)");
   if (hipMemcpyAsync(h->params, params_dev, n_floats * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
     return bail(RGFM_EHIP, "hipMemcpyAsync(params)");
@@ -780,6 +802,27 @@ extern "C" int rgfm_unet_create(const rgfm_unet_desc* desc, const float* params_
   for (ConvW& w : h->down) pack_one(h, w, CONV_S2, s), all.push_back(&w);  // stride-2 convs: phase-ordered weights
   for (ConvW& w : h->up) pack_one(h, w, CONV_S1, s), all.push_back(&w);
   if (read_hx_flags(h->hq, h->n_hq, all, s) != RGFM_OK) return bail(RGFM_EHIP, "reading the fp16 scale records failed");
+  {
+    // The normalised inputs of the fp16 path are S_A silu(gamma xhat + beta): in range for every trained net the
+    // reference can produce, but a conv whose norm parameters are tiny (the activation would sit in the fp16
+    // subnormals) or huge is routed to the split-bf16 kernel here, once, like a conv with out-of-window weights.
+    std::vector<float> host(n_floats);
+    if (hipMemcpyAsync(host.data(), h->params, n_floats * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+      return bail(RGFM_EHIP, "reading the parameters back failed");
+    auto norm_ok = [&](size_t gw, size_t gb, int C) {
+      float mg = 0.f, mb = 0.f;
+      for (int i = 0; i < C; ++i) mg = std::max(mg, std::fabs(host[gw + i])), mb = std::max(mb, std::fabs(host[gb + i]));
+      if (!(mg <= 3.0e38f) || !(mb <= 3.0e38f)) return false;
+      const float hi = 8.f * mg + mb, lo = std::max(mg, mb);  // |gamma xhat + beta| for |xhat| <= 8; the activation's scale
+      return hi < 1024.f && lo >= 0.015625f;
+    };
+    for (auto* v : {&h->enc, &h->mid, &h->dec})
+      for (ResW& r : *v) {
+        if (!norm_ok(r.n1w, r.n1b, r.cin)) r.c1.hx_ok = false;
+        if (!norm_ok(r.n2w, r.n2b, r.cout)) r.c2.hx_ok = false;
+      }
+  }
   launch_pack_conv_out(h->params + h->ocw, h->packed + h->ocw_pk, desc->in_channels, h->final_ch, s);
   // frequency table exp(-ln(1e4) * i / half) in fp32, as torch evaluates it (unet_flexible.py:28-31)
   const int half = h->mc / 2;
@@ -808,7 +851,19 @@ extern "C" void rgfm_unet_destroy(rgfm_unet* h) {
   if (h->packed3) (void)hipFree(h->packed3);
   if (h->freqs) (void)hipFree(h->freqs);
   if (h->lin_dev) (void)hipFree(h->lin_dev);
+  if (h->range_flag) (void)hipFree(h->range_flag);
   delete h;
+}
+
+extern "C" int rgfm_unet_set_conv_mode(rgfm_unet* h, int mode) {
+  if (!h) return fail(RGFM_EINVAL, "null handle");
+  if (int rc = check_conv_mode(mode)) return rc;
+  h->conv_mode = mode;
+  return RGFM_OK;
+}
+extern "C" int rgfm_unet_range_flag(rgfm_unet* h, int* flagged, int reset, rgfm_stream_t stream) {
+  if (!h) return fail(RGFM_EINVAL, "null handle");
+  return read_flag_word(h->range_flag, flagged, reset, (hipStream_t)stream);
 }
 
 static size_t table_bytes(const rgfm_unet* h, int rows) {
@@ -1109,6 +1164,24 @@ int pair_loop(EvalX&& eval_x, EvalY&& eval_y, float* x_inout, float* y_inout, co
     return RGFM_OK;
   };
   hipGraphExec_t exec = nullptr;
+  // On EVERY exit path -- also the error returns inside the loop -- the work already enqueued must stay ordered: the
+  // event that guards the destruction of this call's graph is recorded behind its last launch, and the caller's
+  // stream is joined behind whatever ran on the device's `main` stream (a stale graph_done could let the
+  // next call destroy a graph that is still executing).
+  struct ExitGuard {
+    DevState* ds;
+    hipStream_t s, caller;
+    hipGraphExec_t* exec;
+    bool armed = true;
+    ~ExitGuard() {
+      if (!armed) return;
+      if (*exec) (void)hipEventRecord(ds->graph_done, s);
+      if (s != caller) {
+        (void)hipEventRecord(ds->main_join, s);
+        (void)hipStreamWaitEvent(caller, ds->main_join, 0);
+      }
+    }
+  } exit_guard{ds, s, caller, &exec};
   for (int i = 0; i < ns; ++i) {
     const double t = (double)(step_begin + i) * dtd;
     const bool guided = n_mc > 0 && t > 1e-3;  // `t > eps` test of the reference (:124)
@@ -1129,6 +1202,7 @@ int pair_loop(EvalX&& eval_x, EvalY&& eval_y, float* x_inout, float* y_inout, co
     const int rc = one_step(i, guided);
     if (rc) return rc;
   }
+  exit_guard.armed = false;
   if (exec) HIP_TRY(hipEventRecord(ds->graph_done, s));
   if (s != caller) {
     HIP_TRY(hipEventRecord(ds->main_join, s));
@@ -1787,7 +1861,8 @@ struct rgfm_fmnet {
   unsigned short* packed3 = nullptr;  // 3-plane bf16 conv / deconv weights (conv_mfma_bx3.hip)
   unsigned short* packedh = nullptr;  // 2-plane scaled fp16 conv / deconv weights + scale records (conv_mfma_hx2.hip)
   float* hq = nullptr;
-  unsigned* range_flag = nullptr;
+  unsigned* range_flag = nullptr;  // this handle's range-flag word
+  int conv_mode = -1;              // rgfm_fmnet_set_conv_mode: -1 = RGFM_CONV from the environment
   float* freqs = nullptr;
   size_t n_params = 0, n_packed = 0, n_packed3 = 0, n_packedh = 0;
   int n_hq = 0;
@@ -1847,8 +1922,10 @@ size_t plan_fmnet(const rgfm_fmnet_desc& d, rgfm_fmnet* h) {
     float *pa = h->params, *pp = h->packed, *fr = h->freqs, *hqp = h->hq;
     unsigned short *p3p = h->packed3, *php = h->packedh;
     unsigned* rf = h->range_flag;
+    const int cm = h->conv_mode;
     *h = t;
     h->d = d, h->params = pa, h->packed = pp, h->freqs = fr, h->packed3 = p3p, h->packedh = php, h->hq = hqp, h->range_flag = rf;
+    h->conv_mode = cm;
     h->n_packed = pk.off, h->n_packed3 = p3.off, h->n_packedh = ph.off, h->n_hq = nhq;
   }
   return c.off;
@@ -1932,6 +2009,7 @@ struct FmRun {
 
   // FlowMatchingModel.forward (flow_matching.py:153-173)
   int run(const float* x, float* v_out, float* x_state, float dt) {
+    ModeScope mode_scope(h->conv_mode);
     const int F = h->d.feature_dim, T = h->d.time_emb_dim;
     // ImageEncoder.forward (:56-72)
     Map cur = new_map(32, FM_S, 1);
@@ -2024,7 +2102,7 @@ extern "C" int rgfm_fmnet_create(const rgfm_fmnet_desc* desc, const float* param
   if (hipMalloc(&h->packed3, (h->n_packed3 + 8) * sizeof(unsigned short)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(packed3)");
   if (hipMalloc(&h->packedh, (h->n_packedh + 8) * sizeof(unsigned short)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(packedh)");
   if (hipMalloc(&h->hq, ((size_t)h->n_hq * 4 + 4) * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(hq)");
-  h->range_flag = cur_dev()->range_flag;
+  if (alloc_flag_word(&h->range_flag) != RGFM_OK) return bail(RGFM_ENOMEM, "hipMalloc(range flag)");
   if (hipMemcpyAsync(h->params, params_dev, n_floats * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
     return bail(RGFM_EHIP, "hipMemcpyAsync(params)");
   {
@@ -2069,7 +2147,19 @@ extern "C" void rgfm_fmnet_destroy(rgfm_fmnet* h) {
   if (h->packedh) (void)hipFree(h->packedh);
   if (h->hq) (void)hipFree(h->hq);
   if (h->freqs) (void)hipFree(h->freqs);
+  if (h->range_flag) (void)hipFree(h->range_flag);
   delete h;
+}
+
+extern "C" int rgfm_fmnet_set_conv_mode(rgfm_fmnet* h, int mode) {
+  if (!h) return fail(RGFM_EINVAL, "null handle");
+  if (int rc = check_conv_mode(mode)) return rc;
+  h->conv_mode = mode;
+  return RGFM_OK;
+}
+extern "C" int rgfm_fmnet_range_flag(rgfm_fmnet* h, int* flagged, int reset, rgfm_stream_t stream) {
+  if (!h) return fail(RGFM_EINVAL, "null handle");
+  return read_flag_word(h->range_flag, flagged, reset, (hipStream_t)stream);
 }
 
 extern "C" int rgfm_fmnet_workspace_bytes(const rgfm_fmnet* h, int batch, size_t* bytes) {

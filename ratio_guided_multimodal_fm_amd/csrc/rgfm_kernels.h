@@ -98,6 +98,11 @@ struct ConvArgs {
   const float* hq;
   const float* hq_skip;
   unsigned* range_flag;
+  // 1: a later conv stages this output RAW (no GroupNorm: the fused 1x1 skip, Downsample, Upsample -- reference
+  // unet_flexible.py:85,96,107-108), i.e. as S_A x value in two fp16 planes.  The epilogue then checks the low side of
+  // that representation: a wave block (64 pixels x its channels) whose largest |value| is below HX_SMALL (and not 0)
+  // ORs 2 into *range_flag, and the caller repeats the call on the split-bf16 kernels (fp32 exponent range).
+  int small_check;
   const float* bias; // [Cout]
   const float* temb; // time-embedding add: temb[(per_row ? b : 0) * temb_stride + c]; null = none
   int temb_stride;
@@ -143,6 +148,8 @@ struct ConvInArgs {  // first conv of a net: NCHW image -> NHWC features
   float* stats_out;  // or null
   int B, C0;
   TileGeom g;
+  unsigned* range_flag;  // with small_check (see ConvArgs::small_check): the first conv's output feeds raw consumers too
+  int small_check;
 };
 
 struct ConvOutArgs {  // out_conv(silu(out_norm(h))) -> NCHW velocity, optional fused Euler
@@ -222,6 +229,7 @@ int conv_hx2q_init();
 void conv_hx2q_set_min(int v);  // launches with fewer workgroups than this stay on conv_mfma_hx2p_kernel (0: never used)
 void conv_hx2q_set_target(int v);  // workgroups a launch is cut into when it has the tiles (two per CU)
 void conv_hx2q_set_tpw(int v);     // tools/kbench: force the tiles per workgroup
+void conv_hx2q_set_all(int v);     // tools/kbench: 1 = every supported shape, not only those where it is the faster kernel
 void launch_conv_hx2q(const ConvArgs& a, int mode, hipStream_t s);
 // packs w (mode CONV_S1: [Cout][Cin][taps]; CONV_S2: the phase-major stride-2 order; CONV_T2: a ConvTranspose2d
 // weight [Cin][Cout][4][4], taps ignored) and writes the scale record hq[4] (device)

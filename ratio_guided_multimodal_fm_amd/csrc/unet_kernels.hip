@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const ConvInArgs a) {
     // statistics in one pass around a pivot (the segment's first value): M2 = sum (v-p)^2 - n (mean-p)^2.
     // Keeping all 64 values for a two-pass form needs a fully unrolled loop, which hipcc turns into
     // 256 VGPRs + scratch (it hoists every LDS read), i.e. one wave per SIMD.
-    float sum = 0.f, sq = 0.f, pivot = 0.f;
+    float sum = 0.f, sq = 0.f, pivot = 0.f, vmx = 0.f;
     int r = (q0 + hh) / W, x = (q0 + hh) - r * W;  // incremental raster walk (no per-pixel division)
 #pragma unroll 2
     for (int k = hh; k < nw; k += nh) {
@@ -92,12 +92,19 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const ConvInArgs a) {
         }
       if (a.ep_scale) acc = a.ep_nosilu ? acc * es + eh : silu_f(acc * es + eh);
       a.out[(pix0 + k) * a.C0 + c] = acc;
+      vmx = fmaxf(vmx, fabsf(acc));
       if (k == hh) pivot = acc;
       const float d = acc - pivot;
       sum += d;
       sq += d * d;
       x += nh;
       if (x >= W) x -= W, ++r;
+    }
+    if (a.small_check && a.range_flag) {  // (ConvArgs::small_check; wave-uniform)
+      float m = vmx;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      if (m > 0.f && m < 0.00390625f && lane == 0) atomicOr(a.range_flag, 2u);
     }
     if (a.stats_out && sample_ok && nw > 0) {
       float nme = (float)((nw - hh + nh - 1) / nh);      // pixels this lane saw

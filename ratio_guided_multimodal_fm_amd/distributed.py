@@ -17,8 +17,15 @@ No collective sits inside the Euler loop.  `backend` abstracts the three compute
 calls so that the sharding logic can be exercised with gloo on CPU ranks (the
 tests inject the CPU oracle there); the default backend is the HIP library.
 """
-import torch
-import torch.distributed as dist
+import os
+
+# ROCr reads its flags at hsa_init, i.e. at the first HIP call of the process (torch.cuda.is_available() already is
+# one): the dmabuf-only IPC setting these hosts need must be in the environment BEFORE that, so it is set when this
+# module is imported -- the launchers import it first thing in main(), ahead of set_seed / any torch.cuda call.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 
 def shard_bounds(n, world, rank):
@@ -45,6 +52,10 @@ class HipBackend:
     def sample_pair(self, fm_x, fm_y, x, y, mc_x1, mc_y1, mc_ratios, num_steps, gamma):
         from . import _engine
         return _engine.sample_pair(fm_x, fm_y, x, y, mc_x1, mc_y1, mc_ratios, num_steps, gamma)
+
+    def sample_pair_grad(self, fm_x, fm_y, ratio_estimator, x, y, num_steps, gamma):
+        from . import _engine
+        return _engine.sample_pair_grad(fm_x, fm_y, ratio_estimator, x, y, num_steps, gamma)
 
 
 def _via_host(t, group):
@@ -88,7 +99,13 @@ def sharded_paired_sampler(fm_x, fm_y, ratio_estimator, guidance_method, guidanc
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     x0, y0, mc_x0, mc_y0 = noise
     B = x0.shape[0]
+    if guidance_method not in ('none', 'mc_feng', 'grad_log_ratio'):
+        raise ValueError(f"Unknown guidance_method: {guidance_method}")
     guided = guidance_method == 'mc_feng' and ratio_estimator is not None
+    # gradient guidance needs no MC set: every rank integrates its rows with the estimator's gradient
+    grad_guided = guidance_method == 'grad_log_ratio' and ratio_estimator is not None
+    if grad_guided and not hasattr(backend, "sample_pair_grad"):
+        raise ValueError("this backend has no gradient log-ratio guidance (sample_pair_grad)")
     for m in (fm_x, fm_y, ratio_estimator):
         if m is not None:
             m.eval()
@@ -117,7 +134,10 @@ def sharded_paired_sampler(fm_x, fm_y, ratio_estimator, guidance_method, guidanc
     x = x0[lo:hi].to(device, copy=True).contiguous()
     y = y0[lo:hi].to(device, copy=True).contiguous()
     if hi > lo:
-        backend.sample_pair(fm_x, fm_y, x, y, mc_x1, mc_y1, mc_r, num_steps, guidance_strength)
+        if grad_guided:
+            backend.sample_pair_grad(fm_x, fm_y, ratio_estimator, x, y, num_steps, guidance_strength)
+        else:
+            backend.sample_pair(fm_x, fm_y, x, y, mc_x1, mc_y1, mc_r, num_steps, guidance_strength)
     if not dist.is_initialized():
         return x, y
     counts = [shard_bounds(B, world, r)[1] - shard_bounds(B, world, r)[0] for r in range(world)]
@@ -147,7 +167,6 @@ def init_from_env(backend="nccl"):
     """Process-group setup of a `torch.distributed.run` launch (one process per GPU):
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment, RCCL over xGMI.  Returns (rank, world, device).
     A plain `python` launch (no WORLD_SIZE) is rank 0 of 1 with no process group."""
-    import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -62,6 +62,7 @@ def run_sweep(fm_mnist, fm_svhn, make_ratio, mnist_classifier, svhn_classifier, 
 
 
 def main(argv=None):
+    from . import distributed  # noqa: F401  (first: it puts HSA_ENABLE_IPC_MODE_LEGACY=0 in place before any HIP call of this process)
     p = argparse.ArgumentParser(description='Evaluate MNIST-SVHN guided sampling (MI355X)')
     p.add_argument('--guidance_methods', nargs='+', default=['none', 'mc_feng'])
     p.add_argument('--guidance_strengths', nargs='+', type=float, default=[0.0, 0.5, 1.0])

@@ -25,6 +25,7 @@ def sample_bimodal_guided_mnist_svhn(fm_mnist, fm_svhn, ratio_estimator=None, gu
 
 
 def main(argv=None):
+    from . import distributed  # noqa: F401  (first: it puts HSA_ENABLE_IPC_MODE_LEGACY=0 in place before any HIP call of this process)
     p = argparse.ArgumentParser(description='Sample MNIST-SVHN pairs (MI355X)')
     p.add_argument('--guidance_method', type=str, default='none', choices=['none', 'mc_feng', 'grad_log_ratio'],
                    help="'grad_log_ratio' (v + gamma * grad log r, reference README.md:159-164) is this build's extension: "

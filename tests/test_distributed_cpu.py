@@ -150,3 +150,66 @@ def test_shard_bounds_cover_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_sharded_grad_log_ratio_is_routed_or_refused():
+    """`--sharded --guidance_method grad_log_ratio` must not silently produce unguided samples.  The sharded
+    sampler routes it to the backend's sample_pair_grad on each rank's rows (no MC set is drawn or integrated), and a
+    backend without that call -- or an unknown method -- raises."""
+    import torch
+    from ratio_guided_multimodal_fm_amd.distributed import sharded_paired_sampler
+
+    class Dummy(torch.nn.Module):
+        def forward(self, *a):
+            raise AssertionError("not evaluated")
+
+    calls = []
+
+    class Backend:
+        def sample_single(self, *a):
+            calls.append("single")
+
+        def ratios(self, *a):
+            calls.append("ratios")
+
+        def sample_pair(self, fm_x, fm_y, x, y, mx, my, mr, steps, gamma):
+            calls.append(("pair", mx is None))
+
+        def sample_pair_grad(self, fm_x, fm_y, ratio, x, y, steps, gamma):
+            calls.append(("grad", tuple(x.shape), steps, gamma))
+            x.add_(1.0)
+
+    fx, fy, rr = Dummy(), Dummy(), Dummy()
+    x0, y0 = torch.zeros(5, 1, 4, 4), torch.zeros(5, 3, 4, 4)
+    xs, ys = sharded_paired_sampler(fx, fy, rr, 'grad_log_ratio', 0.7, 9, (x0, y0, None, None), torch.device('cpu'),
+                                    backend=Backend())
+    assert calls == [("grad", (5, 1, 4, 4), 9, 0.7)] and float(xs.min()) == 1.0 and float(x0.max()) == 0.0
+
+    class NoGrad:
+        sample_single, ratios, sample_pair = Backend.sample_single, Backend.ratios, Backend.sample_pair
+
+    nb = NoGrad()
+    with pytest.raises(ValueError):
+        sharded_paired_sampler(fx, fy, rr, 'grad_log_ratio', 0.7, 9, (x0, y0, None, None), torch.device('cpu'), backend=nb)
+    with pytest.raises(ValueError):
+        sharded_paired_sampler(fx, fy, rr, 'no_such_method', 0.7, 9, (x0, y0, None, None), torch.device('cpu'), backend=Backend())
+    # without an estimator the reference's samplers fall back to unguided integration (sample_mnist_svhn.py:85,124)
+    calls.clear()
+    sharded_paired_sampler(fx, fy, None, 'grad_log_ratio', 0.7, 9, (x0, y0, None, None), torch.device('cpu'), backend=Backend())
+    assert calls == [("pair", True)]
+
+
+def test_hsa_ipc_mode_is_set_when_the_launchers_start(monkeypatch):
+    """the dmabuf-IPC setting must be in the environment before the first HIP call of a launcher process:
+    importing the distributed module (the first statement of both launchers' main()) puts it there."""
+    import importlib
+    import os
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    import ratio_guided_multimodal_fm_amd.distributed as d
+    importlib.reload(d)
+    assert os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+    import inspect
+    from ratio_guided_multimodal_fm_amd import evaluate_mnist_svhn, sample_mnist_svhn
+    for mod in (sample_mnist_svhn, evaluate_mnist_svhn):
+        body = inspect.getsource(mod.main).split("\n")
+        assert "from . import distributed" in body[1], body[1]

@@ -119,6 +119,51 @@ def test_config3_rank_shape_through_sharded_sampler(dev):
     assert maxdiff(xg.cpu().numpy(), ox2) < TOL_SAMPLER and maxdiff(yg.cpu().numpy(), oy2) < TOL_SAMPLER
 
 
+def test_config0_full_size_cfm_sampler(dev, monkeypatch):
+    """BASELINE configs[0] at FULL size: CFMSchedule.sample semantics -- MNIST 28x28 net alone, no
+    guidance, batch 64, all 50 Euler steps (reference src/utils/flow_utils.py:69-100) -- first / last rows followed by
+    the CPU oracle over the whole trajectory, and every row compared between the default arithmetic and the exact-fp32
+    MFMA path."""
+    fm = make_module("unet28", dev)
+    B, S = 64, 50
+    x0 = torch.randn(B, 1, 28, 28, generator=torch.Generator().manual_seed(50))
+    xa = x0.to(dev, copy=True)
+    _engine.sample_single(fm, xa, S)
+    monkeypatch.setenv("RGFM_CONV", "f32")
+    xb = x0.to(dev, copy=True)
+    _engine.sample_single(fm, xb, S)
+    monkeypatch.delenv("RGFM_CONV")
+    assert torch.isfinite(xa).all()
+    assert maxdiff(xa.cpu().numpy(), xb.cpu().numpy()) < TOL_SAMPLER
+    d, b = oracle_net("unet28")
+    rows = [0, 1, 31, 62, 63]
+    ox = O.sample_single(d, b, x0[rows].numpy(), S)
+    assert maxdiff(xa[rows].cpu().numpy(), ox) < TOL_SAMPLER
+
+
+def test_config2_own_gamma_all_steps(dev):
+    """BASELINE configs[2] with ITS OWN guidance strength (gamma 0.5; the rank-shape test above runs gamma 1.0): batch
+    512, N_mc 256, ALL 100 steps on the HIP path, eight rows followed by the CPU oracle from the same MC set."""
+    fm, fs, rr = make_module("mnist32", dev), make_module("svhn", dev), make_module("ratio_ms", dev)
+    B, N, S, gamma = 512, 256, 100, 0.5
+    noise = paired_noise(13, B, N, (1, 32, 32), (3, 32, 32))
+    mx1, my1 = noise[2].to(dev, copy=True), noise[3].to(dev, copy=True)
+    _engine.sample_two_streams(fm, mx1, fs, my1, S)
+    r = rr._engine.eval(mx1, my1, "ratio")
+    xa, ya = noise[0].to(dev, copy=True), noise[1].to(dev, copy=True)
+    before = _engine.range_fallbacks
+    _engine.sample_pair(fm, fs, xa, ya, mx1, my1, r, S, gamma)
+    assert _engine.range_fallbacks == before  # the benchmark workload runs on the default arithmetic, no fallback
+    assert torch.isfinite(xa).all() and torch.isfinite(ya).all()
+    dx, bx = oracle_net("mnist32")
+    dy, by = oracle_net("svhn")
+    rows = [0, 1, 127, 255, 256, 383, 510, 511]
+    ox, oy = O.sample_pair(dx, bx, dy, by, noise[0][rows].numpy(), noise[1][rows].numpy(), mx1.cpu().numpy(),
+                           my1.cpu().numpy(), r.cpu().numpy(), S, gamma, 0, S)
+    assert maxdiff(xa[rows].cpu().numpy(), ox) < TOL_SAMPLER
+    assert maxdiff(ya[rows].cpu().numpy(), oy) < TOL_SAMPLER
+
+
 def test_time_embedding_table_against_reference_fixture(dev):
     """a7: the sinusoidal embedding (cos half first, unscaled t; unet_flexible.py:16-36) as the DEVICE evaluates it
     in front of the time MLPs (rgfm_unet_time_embedding), against the reference's timestep_embedding fixture, for

@@ -525,6 +525,77 @@ def test_fp16_range_flag_falls_back_to_bf16(dev, monkeypatch):
     assert float(np.abs(o2 - r2).max() / np.abs(r2).max()) < 1e-5
 
 
+@pytest.mark.parametrize("lg", [-10, -14, -20])
+@pytest.mark.parametrize("kind", ["svhn", "mnist32"])
+def test_fp16_low_range_flag_falls_back_to_bf16(dev, monkeypatch, kind, lg):
+    """The mirror image of the test above: input_conv weights x 2^lg make the un-normalised
+    residual stream ~1e-4 ... 1e-7.  The reference's Downsample / Upsample / 1x1-skip convs consume it in fp32 at any
+    magnitude (unet_flexible.py:85,96,107-108); the fp16 two-plane staging of a raw source (16 a in two fp16 values)
+    loses bits below 2^-8.  The producing conv's epilogue must notice (flag bit 2), the call is repeated on the exact
+    fp32 matrix-core convs -- the reference's arithmetic at any magnitude -- and agrees with RGFM_CONV=f32 to 1e-5
+    relative (it is the same arithmetic; only the GroupNorm plumbing differs)."""
+    from ratio_guided_multimodal_fm_amd import models as M
+    from ratio_guided_multimodal_fm_amd.synth import load_synth
+    m = load_synth(M.FlowMatchingUNetSVHN() if kind == "svhn" else M.FlowMatchingUNetMNIST(img_size=32), 31)
+    with torch.no_grad():
+        m.input_conv.weight.mul_(2.0 ** lg)
+        m.input_conv.bias.mul_(2.0 ** lg)
+    m = m.to(dev).eval()
+    cimg = 3 if kind == "svhn" else 1
+    x = torch.randn(3, cimg, 32, 32, generator=torch.Generator().manual_seed(5)).to(dev)
+    t = torch.tensor([0.1, 0.5, 0.9], device=dev)
+    monkeypatch.setenv("RGFM_CONV", "f32")
+    ref = m(x, t).cpu().numpy().astype(np.float64)
+    monkeypatch.delenv("RGFM_CONV")
+    before = _engine.range_fallbacks
+    out = m(x, t).cpu().numpy().astype(np.float64)
+    assert _engine.range_fallbacks == before + 1 and (_engine.last_range_flags & 2)
+    assert float(np.abs(out - ref).max() / np.abs(ref).max()) < 1e-5
+    # the flag is the handle's own and was consumed by the guarded call; the handle is back on the default arithmetic
+    assert m._engine.read_range_flag(dev) == 0
+    # without the guard the default path's numbers ARE degraded on this net -- the flag is what keeps them out
+    monkeypatch.setenv("RGFM_RANGE_CHECK", "0")
+    raw = m(x, t).cpu().numpy().astype(np.float64)
+    monkeypatch.delenv("RGFM_RANGE_CHECK")
+    assert m._engine.read_range_flag(dev) & 2
+    assert np.isfinite(raw).all()
+
+
+def test_fp16_low_range_flag_inside_the_net(dev, monkeypatch):
+    """A ResBlock whose OUTPUT is tiny (its conv2 and 1x1 skip scaled by 2^-14) in an otherwise ordinary net: the
+    upsampler and the next block's 1x1 skip read that output raw.  Same contract as above; and a second engine on
+    the same device keeps its own flag word (no cross-talk between handles)."""
+    from ratio_guided_multimodal_fm_amd import models as M
+    from ratio_guided_multimodal_fm_amd.synth import load_synth
+    m = load_synth(M.FlowMatchingUNetSVHN(), 31)
+    with torch.no_grad():
+        blk = m.decoder_blocks[2]
+        for p in (blk.conv2.weight, blk.conv2.bias, blk.skip.weight, blk.skip.bias):
+            p.mul_(2.0 ** -14)
+    m = m.to(dev).eval()
+    other = load_synth(M.FlowMatchingUNetSVHN(), 32).to(dev).eval()
+    x = torch.randn(2, 3, 32, 32, generator=torch.Generator().manual_seed(6)).to(dev)
+    t = torch.tensor([0.3, 0.7], device=dev)
+    monkeypatch.setenv("RGFM_CONV", "f32")
+    ref = m(x, t).cpu().numpy().astype(np.float64)
+    monkeypatch.delenv("RGFM_CONV")
+    before = _engine.range_fallbacks
+    o_other = other(x, t)
+    assert _engine.range_fallbacks == before  # an ordinary net does not trip the low-side check
+    out = m(x, t).cpu().numpy().astype(np.float64)
+    assert _engine.range_fallbacks == before + 1 and (_engine.last_range_flags & 2)
+    assert float(np.abs(out - ref).max() / np.abs(ref).max()) < 1e-5
+    assert other._engine.read_range_flag(dev) == 0 and torch.isfinite(o_other).all()
+    # the C-ABI route a non-Python caller takes: switch the handle, no environment involved
+    m._engine.set_conv_mode(dev, _engine.CONV_BX3)
+    monkeypatch.setenv("RGFM_RANGE_CHECK", "0")
+    o2 = m(x, t).cpu().numpy().astype(np.float64)
+    monkeypatch.delenv("RGFM_RANGE_CHECK")
+    m._engine.set_conv_mode(dev, _engine.CONV_DEFAULT)
+    assert m._engine.read_range_flag(dev) == 0
+    assert float(np.abs(o2 - ref).max() / np.abs(ref).max()) < 1e-5
+
+
 def test_same_module_for_both_modalities(dev):
     """sample_bimodal_guided(fm, fm, ...) is legal in the reference: one module (one engine workspace) for both
     modalities must not race in the two-stream pre-phase."""
