@@ -31,9 +31,6 @@ namespace rgfm {
 #ifndef RGFM_HX2Q_ABL
 #define RGFM_HX2Q_ABL 0      // kbench timing ablations (results wrong): 1 no halo staging in the K loop, 2 nor weight DMA,
 #endif                       // 3 nor fragment reads (MFMAs + barriers only), 4: everything but the MFMAs
-#ifndef RGFM_HX2Q_MIX
-#define RGFM_HX2Q_MIX 0      // 1: the early half's staging interleaved with the unit's MFMAs by sched_group_barrier (one stream)
-#endif
 #ifndef RGFM_HX2Q_PRIO
 #define RGFM_HX2Q_PRIO 0     // 1: raised issue priority during a unit's MFMAs
 #endif
@@ -46,15 +43,21 @@ __device__ unsigned long long g_hx2q_prof[16];
 #define QPROF_ACC(i, t0, t1)
 #endif
 
-template <int WL2, bool SKIP>  // SKIP: res_mode == 2 (fused 1x1 skip conv: raw one-tap chunks behind the main chunks)
-__global__ __launch_bounds__(512, 4) void conv_mfma_hx2q_kernel(const ConvArgs a, const int num_tiles, const int tpw, const int nrows) {
+// SKIP: res_mode == 2 (fused 1x1 skip conv: raw one-tap chunks behind the main chunks).  NG: 32-channel groups per
+// workgroup -- 2: 8 waves x <= 128 VGPRs, two workgroups per CU = four waves per SIMD; 1 (Cout = 32: the MNIST net's
+// 32x32 level): 4 waves, two workgroups per CU by LDS = two waves per SIMD, <= 256 VGPRs, twice the halo items per thread.
+template <int WL2, bool SKIP, int NG>
+__global__ __launch_bounds__(256 * NG, NG == 2 ? 4 : 2) void conv_mfma_hx2q_kernel(const ConvArgs a, const int num_tiles, const int tpw, const int nrows) {
   constexpr int W = 1 << WL2, TH = 256 / W, WR = W + 2, HR = TH + 2, HALO = HR * WR;
   constexpr int ABYTES = (HALO + 1) * HRW;  // one halo buffer + a pad record (the store target of lanes past the halo)
-  constexpr int TAPB = 64 * HRW;            // one tap's weight slab: 64 channels
+  constexpr int NTHR = 256 * NG, NW = 4 * NG;
+  constexpr int CB = 32 * NG;               // output channels per workgroup
+  constexpr int TAPB = CB * HRW;            // one tap's weight slab
   constexpr int UB = 3 * TAPB;              // one unit: a kernel row of a 16-channel chunk
+  constexpr int PPT = TAPB / 1024;          // 1-KB DMA pieces per tap
   constexpr int MT_OFF = (32 / W) * WR * HRW;  // pixel p + 32 of a segment: one (W = 32) or two (W = 16) halo rows down, same column
-  constexpr int NIT = 3;                    // halo items (pixel, 4 channels) per thread and chunk: ceil(HALO * 4 / 512)
-  static_assert(HALO * 4 <= NIT * 512 && HALO * 4 > (NIT - 1) * 512, "three items per thread");
+  constexpr int NIT = 6 / NG;               // halo items (pixel, 4 channels) per thread and chunk: ceil(HALO * 4 / NTHR)
+  static_assert(HALO * 4 <= NIT * NTHR && HALO * 4 > (NIT - 1) * NTHR - NTHR, "items per thread");
   extern __shared__ __attribute__((aligned(16))) char smq[];
 #ifdef RGFM_HX2Q_PROF
   long long qacc[3] = {0, 0, 0};
@@ -71,19 +74,19 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_hx2q_kernel(const ConvArgs a
   const int H = a.g.H, tps = a.g.tps;
 
   // workgroup -> (tile group, 64-channel block)
-  const int ncb = a.Cout >> 6;
+  const int ncb = a.Cout / CB;
   const int tg = (int)blockIdx.x / ncb, cb = (int)blockIdx.x - tg * ncb;
   const int tile0 = tg * tpw;
   const int ntw = num_tiles - tile0 < tpw ? num_tiles - tile0 : tpw;  // tiles of this workgroup
   const int bfirst = tile0 / tps, rfirst = tile0 - bfirst * tps;
-  const int n0 = cb * 64 + grp * 32;  // first output channel of this wave
+  const int n0 = cb * CB + grp * 32;  // first output channel of this wave
 
   // ---- consumer-side GroupNorm: scale/shift of this workgroup's sample(s) from the producers' partial statistics
   // (as conv_mfma_hx2p_kernel: one table row per sample; as many waves per row as it takes to give every lane one
   // channel, rows side by side on the waves)
   {
     const int gn_cpg = cin >> 3;
-    int gn_wsh = 3 - (31 - __builtin_clz(nrows));  // log2 (waves / rows): nrows is 1, 2 or 4
+    int gn_wsh = (NG + 1) - (31 - __builtin_clz(nrows));  // log2 (waves / rows): nrows is 1, 2 or 4
     {
       const int need = gn_cpg <= 8 ? 0 : (gn_cpg <= 16 ? 1 : 2);  // (cin <= 256)
       gn_wsh = gn_wsh < need ? gn_wsh : need;
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_hx2q_kernel(const ConvArgs a
         }
       }
     }
-    for (int i = tid; i < 2 * cin; i += 512) sTab[nrows * cin * 2 + i] = 0.f;  // the all-zero row of the padding items
+    for (int i = tid; i < 2 * cin; i += NTHR) sTab[nrows * cin * 2 + i] = 0.f;  // the all-zero row of the padding items
   }
   QPROF_T(tq1);
 
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_hx2q_kernel(const ConvArgs a
   unsigned meta[NIT];
 #pragma unroll
   for (int j = 0; j < NIT; ++j) {
-    const int it = tid + 512 * j;
+    const int it = tid + NTHR * j;
     meta[j] = (unsigned)(HALO * HRW + (q4 >> 1) * 16 + (q4 & 1) * 8) | (1u << 18);
     if (it < HALO * 4) {
       const int hpx = it >> 2;
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_hx2q_kernel(const ConvArgs a
   }
 
   // packed weights: [channel block][chunk][tap] slabs; a workgroup of a 128-channel block takes its 64-channel half
-  const bool nb128 = (a.Cout & 127) == 0;
+  const bool nb128 = NG == 2 && (a.Cout & 127) == 0;  // (NG == 1: Cout % 64 != 0, packed in 32-channel blocks)
   const int TAPS = nb128 ? 2 * TAPB : TAPB;
   const int wblk = nb128 ? cb >> 1 : cb, whalf = nb128 ? (cb & 1) * TAPB : 0;
   const char* const wpk = reinterpret_cast<const char*>(a.wpkh) + (size_t)wblk * nmain * 9 * TAPS + whalf;
@@ -286,9 +289,9 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_hx2q_kernel(const ConvArgs a
     const char* src = main ? wpk + (size_t)u * 3 * TAPS : wsk + (size_t)(u - 3 * nmain) * TAPS;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int pq = wave_s + 8 * j;
-      const int pc = main ? (pq < 12 ? pq : pq - 12) : (pq & 3);
-      const char* gsrc = src + (pc >> 2) * TAPS + (pc & 3) * 1024 + lane * 16;
+      const int pq = wave_s + NW * j;
+      const int pc = main ? (pq < 3 * PPT ? pq : pq - 3 * PPT) : (pq & (PPT - 1));
+      const char* gsrc = src + (pc / PPT) * TAPS + (pc % PPT) * 1024 + lane * 16;
       const unsigned dst = sB_lds + (unsigned)((gun & 1) * UB + pc * 1024);
       unsigned keep;
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -321,7 +324,8 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_hx2q_kernel(const ConvArgs a
     const Pos p1 = succ(cur);
 #pragma unroll
     for (int j = 0; j < NIT; ++j) issue_a(p1, j);
-    HX2Q_WDMA_WAIT(3);  // (the three fetches just issued stay in flight)
+    if (NIT == 3) HX2Q_WDMA_WAIT(3);  // (the fetches just issued stay in flight)
+    else HX2Q_WDMA_WAIT(6);
   }
 
   const float qmain = a.hq[0];
@@ -366,25 +370,12 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_hx2q_kernel(const ConvArgs a
     __builtin_amdgcn_s_setprio(0);
 #endif
   };
-  // RGFM_HX2Q_MIX: ask the scheduler for NM groups of {1 MFMA, 1 LDS read, NV vector-ALU instructions}
-#define HX2Q_MIX_PATTERN(NM, NV)                                   \
-  do {                                                             \
-    _Pragma("unroll") for (int i_ = 0; i_ < (NM); ++i_) {          \
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           \
-      __builtin_amdgcn_sched_group_barrier(0x002, (NV), 0);        \
-    }                                                              \
-  } while (0)
   // the weight half of a unit's staging: the next unit's weights -> the other weight buffer (free since the last barrier)
-#if RGFM_HX2Q_MIX
-#define HX2Q_W_STEP() wdma(u1, gu + 1)
-#else
 #define HX2Q_W_STEP()                       \
   do {                                      \
     wdma(u1, gu + 1);                       \
     __builtin_amdgcn_sched_barrier(0);      \
   } while (0)
-#endif
   // end of a unit: this wave's DMA pieces have landed (N: the halo fetches issued behind them stay in flight), barrier
 #define HX2Q_U_NEXT(N)                      \
   do {                                      \
@@ -409,7 +400,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_hx2q_kernel(const ConvArgs a
     int tid_b = threadIdx.x;
     asm volatile("" : "+v"(tid_b));
     const int seg_b = (tid_b >> 6) & 3, l31_b = tid_b & 31, hp_b = (tid_b >> 5) & 1;
-    const int ch_b = cb * 64 + (tid_b >> 8) * 32 + l31_b;  // this lane's output channel
+    const int ch_b = cb * CB + (tid_b >> 8) * 32 + l31_b;  // this lane's output channel
     const ConvArgs& ka = *kp;
     {
       float v = ka.bias[ch_b];
@@ -452,58 +443,57 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_hx2q_kernel(const ConvArgs a
       const Pos p1 = succ(cur), p2 = succ(p1);
       (void)p2;
 #if RGFM_HX2Q_STAGGER
-      const bool early = grp == 0;
+      const bool early = NG == 2 ? grp == 0 : ((int)blockIdx.x & 1) == 0;
 #else
       constexpr bool early = true;
 #endif
-      // unit 0
-      if (early) {
-        commit_a(xf_tag, p1, gc + 1, 0);
-        HX2Q_W_STEP();
-        issue_a(p2, 0);
-#if RGFM_HX2Q_MIX
-        taps3(0);
-        HX2Q_MIX_PATTERN(18, 2);
-#else
-        __builtin_amdgcn_sched_barrier(0);
-        taps3(0);
-#endif
-      } else {
-        HX2Q_W_STEP();
-        taps3(0);
-        __builtin_amdgcn_sched_barrier(0);
-        commit_a(xf_tag, p1, gc + 1, 0);
-        issue_a(p2, 0);
-      }
-      HX2Q_U_NEXT(1);
-      // unit 1
-      if (early) {
-        commit_a(xf_tag, p1, gc + 1, 1);
-        commit_a(xf_tag, p1, gc + 1, 2);
-        HX2Q_W_STEP();
-        issue_a(p2, 1);
-        issue_a(p2, 2);
-#if RGFM_HX2Q_MIX
-        taps3(1);
-        HX2Q_MIX_PATTERN(18, 4);
-#else
-        __builtin_amdgcn_sched_barrier(0);
-        taps3(1);
-#endif
-      } else {
-        HX2Q_W_STEP();
-        taps3(1);
-        __builtin_amdgcn_sched_barrier(0);
-        commit_a(xf_tag, p1, gc + 1, 1);
-        commit_a(xf_tag, p1, gc + 1, 2);
-        issue_a(p2, 1);
-        issue_a(p2, 2);
-      }
-      HX2Q_U_NEXT(2);
-      // unit 2
-      HX2Q_W_STEP();
-      taps3(2);
-      HX2Q_U_NEXT(0);
+      // the halo items of a unit.  NG == 2 (three items): item 0 in unit 0, items 1 and 2 in unit 1, none in unit 2
+      // (fewer staging sites: the 128-VGPR budget); NG == 1 (six items): j % 3 == U
+      auto commit_items = [&](auto u_tag) {
+        constexpr int U = decltype(u_tag)::value;
+        if constexpr (NG == 2) {
+          if (U == 0) commit_a(xf_tag, p1, gc + 1, 0);
+          if (U == 1) commit_a(xf_tag, p1, gc + 1, 1), commit_a(xf_tag, p1, gc + 1, 2);
+        } else {
+          commit_a(xf_tag, p1, gc + 1, U), commit_a(xf_tag, p1, gc + 1, U + 3);
+        }
+      };
+      auto issue_items = [&](auto u_tag) {
+        constexpr int U = decltype(u_tag)::value;
+        if constexpr (NG == 2) {
+          if (U == 0) issue_a(p2, 0);
+          if (U == 1) issue_a(p2, 1), issue_a(p2, 2);
+        } else {
+          issue_a(p2, U), issue_a(p2, U + 3);
+        }
+      };
+#define HX2Q_UNIT(U)                                             \
+  do {                                                           \
+    using UT = std::integral_constant<int, (U)>;                 \
+    if (NG == 2 && (U) == 2) { /* no halo items in this unit */  \
+      HX2Q_W_STEP();                                             \
+      taps3(U);                                                  \
+    } else if (early) {                                          \
+      commit_items(UT{});                                        \
+      HX2Q_W_STEP();                                             \
+      issue_items(UT{});                                         \
+      __builtin_amdgcn_sched_barrier(0);                         \
+      taps3(U);                                                  \
+    } else {                                                     \
+      HX2Q_W_STEP();                                             \
+      taps3(U);                                                  \
+      __builtin_amdgcn_sched_barrier(0);                         \
+      commit_items(UT{});                                        \
+      issue_items(UT{});                                         \
+    }                                                            \
+    if (NG == 1 || (U) == 1) HX2Q_U_NEXT(2);                     \
+    else if ((U) == 0) HX2Q_U_NEXT(1);                           \
+    else HX2Q_U_NEXT(0);                                         \
+  } while (0)
+      HX2Q_UNIT(0);
+      HX2Q_UNIT(1);
+      HX2Q_UNIT(2);
+#undef HX2Q_UNIT
       ++gc, cur = p1;
     };
 #pragma unroll 1
@@ -516,16 +506,15 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_hx2q_kernel(const ConvArgs a
       acc[0] = acc[0] * rs, acc[1] = acc[1] * rs;
       auto skip_chunk = [&](auto xf_tag) {
         const Pos p1 = succ(cur), p2 = succ(p1);
-        commit_a(xf_tag, p1, gc + 1, 0);
-        commit_a(xf_tag, p1, gc + 1, 1);
-        commit_a(xf_tag, p1, gc + 1, 2);
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) commit_a(xf_tag, p1, gc + 1, j);
         HX2Q_W_STEP();
-        issue_a(p2, 0);
-        issue_a(p2, 1);
-        issue_a(p2, 2);
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) issue_a(p2, j);
         __builtin_amdgcn_sched_barrier(0);
         tap(smq + (gc & 1) * ABYTES + WR * HRW, sB + (gu & 1) * UB, aofs[1]);
-        HX2Q_U_NEXT(3);
+        if (NIT == 3) HX2Q_U_NEXT(3);
+        else HX2Q_U_NEXT(6);
         ++gc, cur = p1;
       };
 #pragma unroll 1
@@ -537,7 +526,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_hx2q_kernel(const ConvArgs a
     int tid_e = threadIdx.x;
     asm volatile("" : "+v"(tid_e));
     const int seg_e = (tid_e >> 6) & 3, l31_e = tid_e & 31, hp_e = (tid_e >> 5) & 1, lane_e = tid_e & 63;
-    const int ch_e = cb * 64 + (tid_e >> 8) * 32 + l31_e;
+    const int ch_e = cb * CB + (tid_e >> 8) * 32 + l31_e;
     const ConvArgs& ke = *kp;
     {
       const float qinv = SKIP ? ke.hq_skip[1] : ke.hq[1];
@@ -615,8 +604,9 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_hx2q_kernel(const ConvArgs a
 }
 
 // ---------------------------------------------------------------- host side
-// launches with fewer workgroups (at one tile each) than this stay on conv_mfma_hx2p_kernel (0: this kernel never runs)
-static int g_hx2q_min = 256;
+// launches with fewer (tile, channel block) pairs than this stay on conv_mfma_hx2p_kernel (0: this kernel never runs):
+// at two workgroups per CU the stream needs >= 2 tiles per workgroup to pay (tools/kbench: B = 128 rows lose)
+static int g_hx2q_min = 1024;
 void conv_hx2q_set_min(int v) { g_hx2q_min = v; }
 static int g_hx2q_target = 512;  // workgroups a launch is cut into when it has the tiles: two per CU
 void conv_hx2q_set_target(int v) { g_hx2q_target = v > 0 ? v : 1; }
@@ -625,9 +615,10 @@ void conv_hx2q_set_all(int v) { g_hx2q_all = v; }
 static int g_hx2q_tpw = 0;       // tools/kbench: force the tiles per workgroup (0: hx2q_tiles_per_wg)
 void conv_hx2q_set_tpw(int v) { g_hx2q_tpw = v; }
 
+static int hx2q_ng(const ConvArgs& a) { return a.Cout % 64 == 0 ? 2 : 1; }  // 32-channel groups per workgroup
 // tiles per workgroup: 1, 2 or 4 -- whole samples or whole fractions of one -- as many as leave `target` workgroups
 static int hx2q_tiles_per_wg(const ConvArgs& a) {
-  const int tiles = geom_num_tiles(a.g, a.B), ncb = a.Cout / 64, tps = a.g.tps;
+  const int tiles = geom_num_tiles(a.g, a.B), ncb = a.Cout / (32 * hx2q_ng(a)), tps = a.g.tps;
   if (g_hx2q_tpw) return g_hx2q_tpw;
   int tpw = 1;
   while (tpw * 2 <= 4 && (tiles / (tpw * 2)) * ncb >= g_hx2q_target && ((tpw * 2) % tps == 0 || tps % (tpw * 2) == 0)) tpw *= 2;
@@ -637,7 +628,7 @@ static int hx2q_rows(const ConvArgs& a, int tpw) { return tpw > a.g.tps ? tpw / 
 
 static size_t hx2q_lds_bytes(const ConvArgs& a, int tpw) {
   const int W = a.g.W, halo = (256 / W + 2) * (W + 2);
-  size_t bytes = (size_t)2 * (halo + 1) * HRW + (size_t)2 * 3 * 64 * HRW;
+  size_t bytes = (size_t)2 * (halo + 1) * HRW + (size_t)2 * 3 * 32 * hx2q_ng(a) * HRW;
   bytes += (size_t)(hx2q_rows(a, tpw) + 1) * (a.C0 + a.C1) * 2 * sizeof(float);
   bytes += (size_t)(a.C0 + a.C1 + (a.res_mode == 2 ? a.R0 + a.R1 : 0));  // 16 bytes per 16-channel chunk: descriptors
   return bytes;
@@ -651,21 +642,32 @@ bool conv_hx2q_supported(const ConvArgs& a, int mode) {
   const TileGeom& g = a.g;
   if (g.spt != 1 || (g.W != 16 && g.W != 32) || g.th * g.W != 256 || g.H % g.th != 0) return false;
   if (a.Hin != g.H || a.Win != g.W) return false;
-  if (a.Cout % 64 != 0 || (a.C0 + a.C1) % KC != 0) return false;
+  if (a.Cout % 32 != 0 || (a.C0 + a.C1) % KC != 0) return false;
   if (a.res_mode == 2 && (a.R0 + a.R1) % KC != 0) return false;
   if (hx2q_lds_bytes(a, hx2q_tiles_per_wg(a)) > 80 * 1024) return false;
-  if (geom_num_tiles(g, a.B) * (a.Cout / 64) < g_hx2q_min) return false;
+  if (geom_num_tiles(g, a.B) * (a.Cout / (32 * hx2q_ng(a))) < g_hx2q_min) return false;
+  {  // the GroupNorm prologue must cut a row over the same number of waves as conv_mfma_hx2p_kernel (bit-identical tables)
+    const int tpw = hx2q_tiles_per_wg(a), rows = hx2q_rows(a, tpw), cpg = (a.C0 + a.C1) / 8;
+    const int need = cpg <= 8 ? 1 : (cpg <= 16 ? 2 : 4);
+    if (4 * hx2q_ng(a) / rows < need) return false;
+  }
   // Where it pays (tools/kbench, same box, B = 512): 64 -> 64 at 32x32 +9..10 %, 128 -> 64 +1 %; with a fused 1x1 skip
   // (192 -> 64: -1.5 %), at 16x16 (-3 %) and with Cout = 128 (two workgroups per tile transform the halo twice:
   // -3..-8 %) conv_mfma_hx2p_kernel is faster.  g_hx2q_all (kbench) lifts the restriction.
   if (g_hx2q_all) return true;
+  // Cout = 32 (the MNIST net's 32x32 level, where a tile has 6-18 units and the per-tile fixed costs dominate):
+  // 32 -> 32 +25..30 %, 64 -> 32 +16 %, 96 -> 32 +2.5 % at B = 512; +10 % / 0 at B = 256
+  if (a.Cout % 64 != 0) return g.W == 32;
   return g.W == 32 && a.Cout == 64 && a.C0 + a.C1 <= 128 && a.res_mode != 2;
 }
 
 int conv_hx2q_init() {
   int rc = 0;
-#define RAISEQ(WL, SK) rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_hx2q_kernel<WL, SK>), \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)
+#define RAISEQ(WL, SK)                                                                                         \
+  rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_hx2q_kernel<WL, SK, 2>),             \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                        \
+  rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_hx2q_kernel<WL, SK, 1>),             \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)
   RAISEQ(4, false); RAISEQ(4, true); RAISEQ(5, false); RAISEQ(5, true);
 #undef RAISEQ
   return rc;
@@ -676,10 +678,14 @@ void launch_conv_hx2q(const ConvArgs& a_in, int mode, hipStream_t s) {
   ConvArgs a = a_in;
   const int tiles = geom_num_tiles(a.g, a.B);
   if (a.fin_ab) a.fin_expected = a.g.tps * 4 * (a.Cout / 32);  // every wave of every tile of a sample arrives
-  const int tpw = hx2q_tiles_per_wg(a), nrows = hx2q_rows(a, tpw);
-  const dim3 grid(((tiles + tpw - 1) / tpw) * (a.Cout / 64));
+  const int tpw = hx2q_tiles_per_wg(a), nrows = hx2q_rows(a, tpw), ng = hx2q_ng(a);
+  const dim3 grid(((tiles + tpw - 1) / tpw) * (a.Cout / (32 * ng)));
   const size_t lds = hx2q_lds_bytes(a, tpw);
-#define LAUNCHQ(WL, SK) hipLaunchKernelGGL((conv_mfma_hx2q_kernel<WL, SK>), grid, dim3(512), lds, s, a, tiles, tpw, nrows)
+#define LAUNCHQ(WL, SK)                                                                                                   \
+  do {                                                                                                                    \
+    if (ng == 2) hipLaunchKernelGGL((conv_mfma_hx2q_kernel<WL, SK, 2>), grid, dim3(512), lds, s, a, tiles, tpw, nrows);   \
+    else hipLaunchKernelGGL((conv_mfma_hx2q_kernel<WL, SK, 1>), grid, dim3(256), lds, s, a, tiles, tpw, nrows);           \
+  } while (0)
   if (a.res_mode == 2) {
     if (a.g.W == 32) LAUNCHQ(5, true);
     else LAUNCHQ(4, true);
