@@ -46,12 +46,15 @@ __device__ unsigned long long g_hx2q_prof[16];
 // SKIP: res_mode == 2 (fused 1x1 skip conv: raw one-tap chunks behind the main chunks).  NG: 32-channel groups per
 // workgroup -- 2: 8 waves x <= 128 VGPRs, two workgroups per CU = four waves per SIMD; 1 (Cout = 32: the MNIST net's
 // 32x32 level): 4 waves, two workgroups per CU by LDS = two waves per SIMD, <= 256 VGPRs, twice the halo items per thread.
-template <int WL2, bool SKIP, int NG>
-__global__ __launch_bounds__(256 * NG, NG == 2 ? 4 : 2) void conv_mfma_hx2q_kernel(const ConvArgs a, const int num_tiles, const int tpw, const int nrows) {
+// NT: 32-channel accumulator columns per wave (1: a 64-pixel x 32-channel wave tile, 2: 64 x 64 as
+// conv_mfma_hx2p_kernel -- two thirds of the fragment reads per MFMA, 256 VGPRs: one (NG = 2) or two (NG = 1)
+// workgroups per CU).
+template <int WL2, bool SKIP, int NG, int NT>
+__global__ __launch_bounds__(256 * NG, (NG == 2 && NT == 1) ? 4 : 2) void conv_mfma_hx2q_kernel(const ConvArgs a, const int num_tiles, const int tpw, const int nrows) {
   constexpr int W = 1 << WL2, TH = 256 / W, WR = W + 2, HR = TH + 2, HALO = HR * WR;
   constexpr int ABYTES = (HALO + 1) * HRW;  // one halo buffer + a pad record (the store target of lanes past the halo)
   constexpr int NTHR = 256 * NG, NW = 4 * NG;
-  constexpr int CB = 32 * NG;               // output channels per workgroup
+  constexpr int CB = 32 * NT * NG;          // output channels per workgroup
   constexpr int TAPB = CB * HRW;            // one tap's weight slab
   constexpr int UB = 3 * TAPB;              // one unit: a kernel row of a 16-channel chunk
   constexpr int PPT = TAPB / 1024;          // 1-KB DMA pieces per tap
@@ -79,7 +82,6 @@ __global__ __launch_bounds__(256 * NG, NG == 2 ? 4 : 2) void conv_mfma_hx2q_kern
   const int tile0 = tg * tpw;
   const int ntw = num_tiles - tile0 < tpw ? num_tiles - tile0 : tpw;  // tiles of this workgroup
   const int bfirst = tile0 / tps, rfirst = tile0 - bfirst * tps;
-  const int n0 = cb * CB + grp * 32;  // first output channel of this wave
 
   // ---- consumer-side GroupNorm: scale/shift of this workgroup's sample(s) from the producers' partial statistics
   // (as conv_mfma_hx2p_kernel: one table row per sample; as many waves per row as it takes to give every lane one
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(256 * NG, NG == 2 ? 4 : 2) void conv_mfma_hx2q_kern
   }
   int bofs;
   {
-    const int rec = grp * 32 + l31;
+    const int rec = grp * 32 * NT + l31;  // (column nt: 32 records = 2048 bytes further, same swizzle)
     bofs = rec * HRW + ((hp ^ (rec >> 2)) & 3) * 16;
   }
 
@@ -207,7 +209,9 @@ __global__ __launch_bounds__(256 * NG, NG == 2 ? 4 : 2) void conv_mfma_hx2q_kern
   }
 
   // packed weights: [channel block][chunk][tap] slabs; a workgroup of a 128-channel block takes its 64-channel half
-  const bool nb128 = NG == 2 && (a.Cout & 127) == 0;  // (NG == 1: Cout % 64 != 0, packed in 32-channel blocks)
+  // (the weights are packed in blocks of 128 / 64 / 32 channels -- hx2_block_channels; conv_hx2q_supported lets a
+  // workgroup cover a whole block, or half of a 128-channel one)
+  const bool nb128 = CB == 64 && (a.Cout & 127) == 0;
   const int TAPS = nb128 ? 2 * TAPB : TAPB;
   const int wblk = nb128 ? cb >> 1 : cb, whalf = nb128 ? (cb & 1) * TAPB : 0;
   const char* const wpk = reinterpret_cast<const char*>(a.wpkh) + (size_t)wblk * nmain * 9 * TAPS + whalf;
@@ -287,8 +291,9 @@ __global__ __launch_bounds__(256 * NG, NG == 2 ? 4 : 2) void conv_mfma_hx2q_kern
   auto wdma = [&](int u, int gun) {
     const bool main = u < 3 * nmain;
     const char* src = main ? wpk + (size_t)u * 3 * TAPS : wsk + (size_t)(u - 3 * nmain) * TAPS;
+    constexpr int NPW = (3 * PPT + NW - 1) / NW;  // pieces per wave
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NPW; ++j) {
       const int pq = wave_s + NW * j;
       const int pc = main ? (pq < 3 * PPT ? pq : pq - 3 * PPT) : (pq & (PPT - 1));
       const char* gsrc = src + (pc / PPT) * TAPS + (pc % PPT) * 1024 + lane * 16;
@@ -329,13 +334,15 @@ __global__ __launch_bounds__(256 * NG, NG == 2 ? 4 : 2) void conv_mfma_hx2q_kern
   }
 
   const float qmain = a.hq[0];
-  f32x16 acc[2];
+  f32x16 acc[2][NT];
   // one tap (kernel column KX of the halo row at sArow): 6 fragment reads, 6 MFMAs (a_l w_h, a_h w_l, a_h w_h per tile)
   auto tap = [&](const char* sArow, const char* sBt, int o0) {
-    f16x8 af[2][2], bf[2];
+    f16x8 af[2][2], bf[NT][2];
     const int o1 = o0 ^ 32;
 #if RGFM_HX2Q_ABL == 3
-    af[0][0] = af[0][1] = af[1][0] = af[1][1] = bf[0] = bf[1] = __builtin_bit_cast(f16x8, ra[0]);
+    af[0][0] = af[0][1] = af[1][0] = af[1][1] = __builtin_bit_cast(f16x8, ra[0]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bf[nt][0] = bf[nt][1] = af[0][0];
     (void)sArow, (void)sBt, (void)o1;
     if (false)
 #endif
@@ -344,17 +351,23 @@ __global__ __launch_bounds__(256 * NG, NG == 2 ? 4 : 2) void conv_mfma_hx2q_kern
     af[0][1] = *reinterpret_cast<const f16x8*>(sArow + o1);
     af[1][0] = *reinterpret_cast<const f16x8*>(sArow + o0 + MT_OFF);
     af[1][1] = *reinterpret_cast<const f16x8*>(sArow + o1 + MT_OFF);
-    bf[0] = *reinterpret_cast<const f16x8*>(sBt + bofs);
-    bf[1] = *reinterpret_cast<const f16x8*>(sBt + (bofs ^ 32));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      bf[nt][0] = *reinterpret_cast<const f16x8*>(sBt + bofs + nt * 32 * HRW);
+      bf[nt][1] = *reinterpret_cast<const f16x8*>(sBt + (bofs ^ 32) + nt * 32 * HRW);
+    }
     }
     constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
 #if RGFM_HX2Q_ABL == 4
-    asm volatile("" :: "v"(af[0][0]), "v"(af[0][1]), "v"(af[1][0]), "v"(af[1][1]), "v"(bf[0]), "v"(bf[1]));
+    asm volatile("" :: "v"(af[0][0]), "v"(af[0][1]), "v"(af[1][0]), "v"(af[1][1]), "v"(bf[0][0]), "v"(bf[0][1]));
 #else
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt][PA[q]], bf[PB[q]], acc[mt], 0, 0, 0);
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt][PA[q]], bf[nt][PB[q]], acc[mt][nt], 0, 0, 0);
 #endif
   };
   auto taps3 = [&](int U) {
@@ -400,30 +413,41 @@ __global__ __launch_bounds__(256 * NG, NG == 2 ? 4 : 2) void conv_mfma_hx2q_kern
     int tid_b = threadIdx.x;
     asm volatile("" : "+v"(tid_b));
     const int seg_b = (tid_b >> 6) & 3, l31_b = tid_b & 31, hp_b = (tid_b >> 5) & 1;
-    const int ch_b = cb * CB + (tid_b >> 8) * 32 + l31_b;  // this lane's output channel
+    const int ch_b = cb * CB + (tid_b >> 8) * 32 * NT + l31_b;  // this lane's first output channel (column nt: + 32 nt)
     const ConvArgs& ka = *kp;
     {
-      float v = ka.bias[ch_b];
-      if (SKIP) v += ka.skip_bias[ch_b];
-      if (ka.temb) v += ka.temb[((size_t)(ka.temb_per_row ? tb : 0) + (ka.step_ptr ? (size_t)*ka.step_ptr : 0)) * ka.temb_stride + ch_b];
-      const float add0 = v * qmain;
+      float add0[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int c = ch_b + nt * 32;
+        float v = ka.bias[c];
+        if (SKIP) v += ka.skip_bias[c];
+        if (ka.temb) v += ka.temb[((size_t)(ka.temb_per_row ? tb : 0) + (ka.step_ptr ? (size_t)*ka.step_ptr : 0)) * ka.temb_stride + c];
+        add0[nt] = v * qmain;
+      }
       if (!SKIP && ka.res_mode == 1) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int p = 64 * seg_b + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hp_b;
-            acc[mt][r] = ka.res0[(size_t)(__umul24((unsigned)pix0 + (unsigned)p, (unsigned)ka.Cout) + (unsigned)ch_b)];
+            const float* rp = ka.res0 + (size_t)(__umul24((unsigned)pix0 + (unsigned)p, (unsigned)ka.Cout) + (unsigned)ch_b);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] = rp[nt * 32];
           }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[mt][r] = fmaf(acc[mt][r], qmain, add0);
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = fmaf(acc[mt][nt][r], qmain, add0[nt]);
       } else {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[mt][r] = add0;
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = add0[nt];
       }
     }
     if (t == 0) __syncthreads();  // (the fill's stores)
@@ -503,7 +527,10 @@ __global__ __launch_bounds__(256 * NG, NG == 2 ? 4 : 2) void conv_mfma_hx2q_kern
     } else {  // the 1x1 skip weights carry their own scale: q_main -> q_skip; one unit per chunk (the centre tap)
       main_chunk(std::false_type{});
       const float rs = a.hq_skip[0] * a.hq[1];
-      acc[0] = acc[0] * rs, acc[1] = acc[1] * rs;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc[mt][nt] * rs;
       auto skip_chunk = [&](auto xf_tag) {
         const Pos p1 = succ(cur), p2 = succ(p1);
 #pragma unroll
@@ -526,11 +553,14 @@ __global__ __launch_bounds__(256 * NG, NG == 2 ? 4 : 2) void conv_mfma_hx2q_kern
     int tid_e = threadIdx.x;
     asm volatile("" : "+v"(tid_e));
     const int seg_e = (tid_e >> 6) & 3, l31_e = tid_e & 31, hp_e = (tid_e >> 5) & 1, lane_e = tid_e & 63;
-    const int ch_e = cb * CB + (tid_e >> 8) * 32 + l31_e;
+    const int ch_e = cb * CB + (tid_e >> 8) * 32 * NT + l31_e;
     const ConvArgs& ke = *kp;
     {
       const float qinv = SKIP ? ke.hq_skip[1] : ke.hq[1];
-      acc[0] = acc[0] * qinv, acc[1] = acc[1] * qinv;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc[mt][nt] * qinv;
     }
     // ---------------------------------------------------------------- epilogue: every pixel of the tile is valid
 #pragma unroll
@@ -538,28 +568,33 @@ __global__ __launch_bounds__(256 * NG, NG == 2 ? 4 : 2) void conv_mfma_hx2q_kern
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int p = 64 * seg_e + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hp_e;
-        ke.out[(size_t)(__umul24((unsigned)pix0 + (unsigned)p, (unsigned)ke.Cout) + (unsigned)ch_e)] = acc[mt][r];
+        float* op = ke.out + (size_t)(__umul24((unsigned)pix0 + (unsigned)p, (unsigned)ke.Cout) + (unsigned)ch_e);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) op[nt * 32] = acc[mt][nt][r];
       }
     if (ke.stats_out) {
       const int nparts = ke.g.nparts;
       const int part = tr * 4 + seg_e;
-      float s = 0.f;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int nt = 0; nt < NT; ++nt) {
+        float s = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s += acc[mt][r];
-      s += __shfl_xor(s, 32);
-      const float mean = s / 64.f;
-      float m2 = 0.f;
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+          for (int r = 0; r < 16; ++r) s += acc[mt][nt][r];
+        s += __shfl_xor(s, 32);
+        const float mean = s / 64.f;
+        float m2 = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float d = acc[mt][r] - mean;
-          m2 += d * d;
-        }
-      m2 += __shfl_xor(m2, 32);
-      if (hp_e == 0) store_stats(ke, ke.stats_out + (((size_t)tb * nparts + part) * ke.Cout + ch_e) * 2, mean, m2);
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float d = acc[mt][nt][r] - mean;
+            m2 += d * d;
+          }
+        m2 += __shfl_xor(m2, 32);
+        if (hp_e == 0) store_stats(ke, ke.stats_out + (((size_t)tb * nparts + part) * ke.Cout + ch_e + nt * 32) * 2, mean, m2);
+      }
       if (ke.fin_ab) fin_arrive(ke, tb, lane_e, nparts, false);
     }
     if (ke.small_check && ke.range_flag) {  // (ConvArgs::small_check: the output's low range)
@@ -567,7 +602,9 @@ __global__ __launch_bounds__(256 * NG, NG == 2 ? 4 : 2) void conv_mfma_hx2q_kern
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(acc[mt][r]));
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(acc[mt][nt][r]));
       hx_small_flag(ke.range_flag, m);
     }
     QPROF_T(tt3);
@@ -614,21 +651,37 @@ static int g_hx2q_all = 0;       // tools/kbench: every supported shape, not onl
 void conv_hx2q_set_all(int v) { g_hx2q_all = v; }
 static int g_hx2q_tpw = 0;       // tools/kbench: force the tiles per workgroup (0: hx2q_tiles_per_wg)
 void conv_hx2q_set_tpw(int v) { g_hx2q_tpw = v; }
+static int g_hx2q_cut = 0;       // tools/kbench: force the workgroup cut, 10 NG + NT (0: hx2q_cut)
+void conv_hx2q_set_cut(int v) { g_hx2q_cut = v; }
 
-static int hx2q_ng(const ConvArgs& a) { return a.Cout % 64 == 0 ? 2 : 1; }  // 32-channel groups per workgroup
+// The workgroup cut {NG 32 NT-channel groups, NT accumulator columns per wave} -> channels per workgroup 32 NG NT:
+//   {1,1} 32 ch, 4 waves, two workgroups per CU (LDS)      {2,1} 64 ch, 8 waves x 128 VGPRs, two workgroups per CU
+//   {1,2} 64 ch, 4 waves x 256 VGPRs, two workgroups per CU  {2,2} 128 ch, 8 waves x 256 VGPRs, one workgroup per CU
+struct Hx2qCut {
+  int ng, nt;
+  int cb() const { return 32 * ng * nt; }
+};
+static Hx2qCut hx2q_cut(const ConvArgs& a) {
+  if (g_hx2q_cut) return {g_hx2q_cut / 10, g_hx2q_cut % 10};
+  if (a.Cout % 64 != 0) return {1, 1};
+  return {2, 1};
+}
 // tiles per workgroup: 1, 2 or 4 -- whole samples or whole fractions of one -- as many as leave `target` workgroups
+// (half of it for the one-workgroup-per-CU cut)
 static int hx2q_tiles_per_wg(const ConvArgs& a) {
-  const int tiles = geom_num_tiles(a.g, a.B), ncb = a.Cout / (32 * hx2q_ng(a)), tps = a.g.tps;
+  const Hx2qCut c = hx2q_cut(a);
+  const int tiles = geom_num_tiles(a.g, a.B), ncb = a.Cout / c.cb(), tps = a.g.tps;
   if (g_hx2q_tpw) return g_hx2q_tpw;
+  const int target = (c.ng == 2 && c.nt == 2) ? g_hx2q_target / 2 : g_hx2q_target;
   int tpw = 1;
-  while (tpw * 2 <= 4 && (tiles / (tpw * 2)) * ncb >= g_hx2q_target && ((tpw * 2) % tps == 0 || tps % (tpw * 2) == 0)) tpw *= 2;
+  while (tpw * 2 <= 4 && (tiles / (tpw * 2)) * ncb >= target && ((tpw * 2) % tps == 0 || tps % (tpw * 2) == 0)) tpw *= 2;
   return tpw;
 }
 static int hx2q_rows(const ConvArgs& a, int tpw) { return tpw > a.g.tps ? tpw / a.g.tps : 1; }
 
 static size_t hx2q_lds_bytes(const ConvArgs& a, int tpw) {
   const int W = a.g.W, halo = (256 / W + 2) * (W + 2);
-  size_t bytes = (size_t)2 * (halo + 1) * HRW + (size_t)2 * 3 * 32 * hx2q_ng(a) * HRW;
+  size_t bytes = (size_t)2 * (halo + 1) * HRW + (size_t)2 * 3 * hx2q_cut(a).cb() * HRW;
   bytes += (size_t)(hx2q_rows(a, tpw) + 1) * (a.C0 + a.C1) * 2 * sizeof(float);
   bytes += (size_t)(a.C0 + a.C1 + (a.res_mode == 2 ? a.R0 + a.R1 : 0));  // 16 bytes per 16-channel chunk: descriptors
   return bytes;
@@ -642,14 +695,22 @@ bool conv_hx2q_supported(const ConvArgs& a, int mode) {
   const TileGeom& g = a.g;
   if (g.spt != 1 || (g.W != 16 && g.W != 32) || g.th * g.W != 256 || g.H % g.th != 0) return false;
   if (a.Hin != g.H || a.Win != g.W) return false;
-  if (a.Cout % 32 != 0 || (a.C0 + a.C1) % KC != 0) return false;
+  if ((a.C0 + a.C1) % KC != 0) return false;
   if (a.res_mode == 2 && (a.R0 + a.R1) % KC != 0) return false;
-  if (hx2q_lds_bytes(a, hx2q_tiles_per_wg(a)) > 80 * 1024) return false;
-  if (geom_num_tiles(g, a.B) * (a.Cout / (32 * hx2q_ng(a))) < g_hx2q_min) return false;
+  const Hx2qCut c = hx2q_cut(a);
+#ifndef RGFM_HX2Q_ALL_CUTS
+  if (c.nt != 1) return false;
+#endif
+  // a workgroup covers one packed weight block (128 / 64 / 32 channels: hx2_block_channels) or half of a 128-channel one
+  const int nb = a.Cout % 128 == 0 ? 128 : (a.Cout % 64 == 0 ? 64 : 32);
+  if (a.Cout % c.cb() != 0 || !(c.cb() == nb || (c.cb() == 64 && nb == 128))) return false;
+  const int tpw = hx2q_tiles_per_wg(a);
+  if (hx2q_lds_bytes(a, tpw) > ((c.ng == 2 && c.nt == 2) ? 160 : 80) * 1024) return false;
+  if (geom_num_tiles(g, a.B) * (a.Cout / c.cb()) < g_hx2q_min) return false;
   {  // the GroupNorm prologue must cut a row over the same number of waves as conv_mfma_hx2p_kernel (bit-identical tables)
-    const int tpw = hx2q_tiles_per_wg(a), rows = hx2q_rows(a, tpw), cpg = (a.C0 + a.C1) / 8;
+    const int rows = hx2q_rows(a, tpw), cpg = (a.C0 + a.C1) / 8;
     const int need = cpg <= 8 ? 1 : (cpg <= 16 ? 2 : 4);
-    if (4 * hx2q_ng(a) / rows < need) return false;
+    if (4 * c.ng / rows < need) return false;
   }
   // Where it pays (tools/kbench, same box, B = 512): 64 -> 64 at 32x32 +9..10 %, 128 -> 64 +1 %; with a fused 1x1 skip
   // (192 -> 64: -1.5 %), at 16x16 (-3 %) and with Cout = 128 (two workgroups per tile transform the halo twice:
@@ -661,14 +722,29 @@ bool conv_hx2q_supported(const ConvArgs& a, int mode) {
   return g.W == 32 && a.Cout == 64 && a.C0 + a.C1 <= 128 && a.res_mode != 2;
 }
 
+// The cuts with 64-channel wave tiles are built for tools/kbench only (-DRGFM_HX2Q_ALL_CUTS): measured against
+// conv_mfma_hx2p_kernel over every layer shape of the two U-Nets at B = 512 (tools/kbench/scripts/q11.sh), {1,2} is
+// 2..25 % slower everywhere and {2,2} -- conv_mfma_hx2p's own tile behind the tile stream -- within +-2 %: the stream
+// pays where a tile's K loop is short (Cout <= 64 at 32x32), not where hx2p's interleaved units already hide the
+// per-tile costs.
+#ifdef RGFM_HX2Q_ALL_CUTS
+#define HX2Q_FOR_ALL(X) \
+  X(4, false, 1, 1) X(4, true, 1, 1) X(5, false, 1, 1) X(5, true, 1, 1) \
+  X(4, false, 2, 1) X(4, true, 2, 1) X(5, false, 2, 1) X(5, true, 2, 1) \
+  X(4, false, 1, 2) X(4, true, 1, 2) X(5, false, 1, 2) X(5, true, 1, 2) \
+  X(4, false, 2, 2) X(4, true, 2, 2) X(5, false, 2, 2) X(5, true, 2, 2)
+#else
+#define HX2Q_FOR_ALL(X) \
+  X(4, false, 1, 1) X(4, true, 1, 1) X(5, false, 1, 1) X(5, true, 1, 1) \
+  X(4, false, 2, 1) X(4, true, 2, 1) X(5, false, 2, 1) X(5, true, 2, 1)
+#endif
+
 int conv_hx2q_init() {
   int rc = 0;
-#define RAISEQ(WL, SK)                                                                                         \
-  rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_hx2q_kernel<WL, SK, 2>),             \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                        \
-  rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_hx2q_kernel<WL, SK, 1>),             \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)
-  RAISEQ(4, false); RAISEQ(4, true); RAISEQ(5, false); RAISEQ(5, true);
+#define RAISEQ(WL, SK, G, T)                                                                               \
+  rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_hx2q_kernel<WL, SK, G, T>),     \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, ((G) == 2 && (T) == 2 ? 160 : 80) * 1024);
+  HX2Q_FOR_ALL(RAISEQ)
 #undef RAISEQ
   return rc;
 }
@@ -677,23 +753,19 @@ void launch_conv_hx2q(const ConvArgs& a_in, int mode, hipStream_t s) {
   (void)mode;
   ConvArgs a = a_in;
   const int tiles = geom_num_tiles(a.g, a.B);
-  if (a.fin_ab) a.fin_expected = a.g.tps * 4 * (a.Cout / 32);  // every wave of every tile of a sample arrives
-  const int tpw = hx2q_tiles_per_wg(a), nrows = hx2q_rows(a, tpw), ng = hx2q_ng(a);
-  const dim3 grid(((tiles + tpw - 1) / tpw) * (a.Cout / (32 * ng)));
+  const Hx2qCut c = hx2q_cut(a);
+  if (a.fin_ab) a.fin_expected = a.g.tps * 4 * (a.Cout / (32 * c.nt));  // every wave of every tile of a sample arrives
+  const int tpw = hx2q_tiles_per_wg(a), nrows = hx2q_rows(a, tpw);
+  const dim3 grid(((tiles + tpw - 1) / tpw) * (a.Cout / c.cb()));
   const size_t lds = hx2q_lds_bytes(a, tpw);
-#define LAUNCHQ(WL, SK)                                                                                                   \
-  do {                                                                                                                    \
-    if (ng == 2) hipLaunchKernelGGL((conv_mfma_hx2q_kernel<WL, SK, 2>), grid, dim3(512), lds, s, a, tiles, tpw, nrows);   \
-    else hipLaunchKernelGGL((conv_mfma_hx2q_kernel<WL, SK, 1>), grid, dim3(256), lds, s, a, tiles, tpw, nrows);           \
-  } while (0)
-  if (a.res_mode == 2) {
-    if (a.g.W == 32) LAUNCHQ(5, true);
-    else LAUNCHQ(4, true);
-  } else {
-    if (a.g.W == 32) LAUNCHQ(5, false);
-    else LAUNCHQ(4, false);
-  }
+  const int wl = a.g.W == 32 ? 5 : 4;
+  const bool sk = a.res_mode == 2;
+#define LAUNCHQ(WL, SK, G, T)                                                                                         \
+  if (wl == (WL) && sk == (SK) && c.ng == (G) && c.nt == (T))                                                         \
+    hipLaunchKernelGGL((conv_mfma_hx2q_kernel<WL, SK, G, T>), grid, dim3(256 * (G)), lds, s, a, tiles, tpw, nrows);
+  HX2Q_FOR_ALL(LAUNCHQ)
 #undef LAUNCHQ
 }
+#undef HX2Q_FOR_ALL
 
 }  // namespace rgfm

@@ -229,6 +229,7 @@ int conv_hx2q_init();
 void conv_hx2q_set_min(int v);  // launches with fewer workgroups than this stay on conv_mfma_hx2p_kernel (0: never used)
 void conv_hx2q_set_target(int v);  // workgroups a launch is cut into when it has the tiles (two per CU)
 void conv_hx2q_set_tpw(int v);     // tools/kbench: force the tiles per workgroup
+void conv_hx2q_set_cut(int v);     // tools/kbench: force the workgroup cut (10 NG + NT: 11, 21, 12, 22)
 void conv_hx2q_set_all(int v);     // tools/kbench: 1 = every supported shape, not only those where it is the faster kernel
 void launch_conv_hx2q(const ConvArgs& a, int mode, hipStream_t s);
 // packs w (mode CONV_S1: [Cout][Cin][taps]; CONV_S2: the phase-major stride-2 order; CONV_T2: a ConvTranspose2d

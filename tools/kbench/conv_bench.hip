@@ -68,6 +68,7 @@ int main(int argc, char** argv) {
   if (getenv("RGFM_HX2Q_MIN")) conv_hx2q_set_min(atoi(getenv("RGFM_HX2Q_MIN")));
   if (getenv("RGFM_HX2Q_TPW")) conv_hx2q_set_tpw(atoi(getenv("RGFM_HX2Q_TPW")));
   conv_hx2q_set_all(1);
+  if (getenv("RGFM_HX2Q_CUT")) conv_hx2q_set_cut(atoi(getenv("RGFM_HX2Q_CUT")));
   if (getenv("RGFM_HX2P_W4")) conv_hx2p_set_w4(atoi(getenv("RGFM_HX2P_W4")));
   if (getenv("RGFM_HX2P_HALF")) conv_hx2p_set_half(atoi(getenv("RGFM_HX2P_HALF")));
 #if RGFM_HX2P_QEXP
