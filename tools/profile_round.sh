@@ -25,7 +25,12 @@ echo "kernel stats done"
 rm -rf /tmp/kt && RGFM_OVERLAP=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- \
   python3 $R/bench.py --steps 1 --warmup 1 --euler-steps 4 --no-kernel-timers $B > /dev/null 2>&1 || exit 1
 cp $(find /tmp/kt -name '*kernel_stats.csv' | head -1) $O/${TAG}_bench_kernel_stats_serial.csv
-python3 $R/tools/trace_layers.py $(find /tmp/kt -name '*kernel_trace.csv' | head -1) 512 > $O/${TAG}_bench_layers_serial.txt 2>&1
+# per-layer roofline against the ceilings the bench line of step 1 measured in-process (f16 MFMA loop / 3, float4 copy)
+CEIL=$(python3 -c "
+import json
+d=json.loads(open('$O/${TAG}_bench_line.json').read().strip().splitlines()[-1])['roofline']['measured_ceilings']
+print(round(d['mfma_f16_tflops']/3,1), round(d['hbm_copy_gbs']/1000,2))")
+python3 $R/tools/trace_layers.py $(find /tmp/kt -name '*kernel_trace.csv' | head -1) 512 $CEIL > $O/${TAG}_bench_layers_serial.txt 2>&1
 echo "layers done"
 
 # 4. PMC: clock + MFMA busy (own pass, kernel trace only)

@@ -67,7 +67,7 @@ def main():
     # per-layer roofline against the MEASURED ceilings of the bench line (roofline.measured_ceilings): the f16-MFMA
     # loop / 3 products, and the float4 copy rate; bytes = input + residual or skip source + output, once each
     mf = float(sys.argv[3]) if len(sys.argv) > 3 else 565.0   # TFLOP/s fp32-equivalent
-    bw = float(sys.argv[4]) if len(sys.argv) > 4 else 4.5     # TB/s
+    bw = float(sys.argv[4]) if len(sys.argv) > 4 else 5.9     # TB/s (rgfm_ubench_hbm_copy: eight loads in flight per thread)
     print(f"{'layer':16s} {'S':>3s} {'cin':>4s} {'cout':>4s} {'grid':>10s} {'us':>8s} {'TF/s':>7s} {'MB':>6s} {'roof us':>8s} {'bound':>5s} {'frac':>5s}")
     # launch order inside a step: SVHN net first (side stream), then the MNIST net
     for (name, mode, S, cin, cout, sk), (t0, t1, kn, gx, gy) in zip([("s." + a[0],) + a[1:] for a in sv] +
