@@ -484,6 +484,19 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2_kernel(const ConvArgs a,
   auto epilogue = [&](auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
     unsigned vmask[2] = {0u, 0u};
+    if (a.ep_scale) {  // folded eval-mode BatchNorm (+ SiLU) of the ratio estimators' encoders, as conv_mfma.hip
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float es = a.ep_scale[n0 + nt * 32 + l31], eh = a.ep_shift[n0 + nt * 32 + l31];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[mt][nt][r] * es + eh;
+            acc[mt][nt][r] = a.ep_nosilu ? v : silu_f(v);
+          }
+      }
+    }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -728,7 +741,7 @@ static size_t hx2_lds_bytes(const ConvArgs& a, int mode) {
   return bytes;
 }
 bool conv_hx2_supported(const ConvArgs& a, int mode) {
-  if (!a.wpkh || !a.hq || !a.range_flag || a.ep_scale) return false;  // (the BatchNorm+SiLU epilogue of the ratio nets stays on conv_mfma.hip)
+  if (!a.wpkh || !a.hq || !a.range_flag) return false;
   if (a.res_mode == 2 && (!a.wskiph || !a.hq_skip)) return false;
   // 24-bit pixel indices and 32-bit element offsets inside the kernel (B = 8192 rows of 32x32x256 still fit)
   const size_t px_in = (size_t)a.B * a.Hin * a.Win, px_out = (size_t)a.B * a.g.HW * (mode == CONV_T2 ? 4 : 1);

@@ -25,8 +25,8 @@
 // latency-bound on everything it does there -- ~280 cycles per global_load_lds issue, ~800 per LDS round trip, 8.5
 // cycles per VALU instruction beside two MFMA waves -- so the eight consumers waited for it at every barrier.
 //
-// The external scale/shift array path (ConvArgs::ab without gn_stats0) and the stride-2 / transposed modes stay on
-// conv_mfma_hx2_kernel.
+// The stride-2 / transposed modes stay on conv_mfma_hx2_kernel.  An external scale/shift array (ConvArgs::ab without
+// gn_stats0) is copied into the same LDS table the consumer-side norm fills (round 3).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -99,7 +99,8 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, (RGFM_HX2P_QEXP
   char* const sB = smemp + 2 * abytes;         // two unit-sized weight buffers
   float* const sTab = reinterpret_cast<float*>(sB + 2 * UB);  // [NA * spt][cin][2] S_A x (scale, shift) + a zero row
   // per 16-channel chunk: {source pointer of the chunk's first channel (lo, hi), channel stride of that source, -}
-  char* const sDesc = reinterpret_cast<char*>(sTab) + (a.gn_stats0 ? (size_t)(NA * a.g.spt + 1) * (a.C0 + a.C1) * 8 : 0);
+  const bool has_tab = a.gn_stats0 != nullptr || a.ab != nullptr;  // a scale/shift table: from the statistics, or from an external array
+  char* const sDesc = reinterpret_cast<char*>(sTab) + (has_tab ? (size_t)(NA * a.g.spt + 1) * (a.C0 + a.C1) * 8 : 0);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = W4 ? 0 : wave >> 2, seg = wave & 3;
@@ -460,7 +461,22 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, (RGFM_HX2P_QEXP
     // (visible to every wave after the barrier that opens commit(0))
   }
 
-  if (a.gn_stats0)  // the all-zero row of the padding items
+  if (!a.gn_stats0 && a.ab) {
+    // external scale/shift array ab[B][cin][2] (RGFM_GN=table; the ratio encoders' "SiLU on load" identity pairs):
+    // the same table, S_A x (scale, shift) of every sample slot of this block, copied instead of derived
+    const int cin_t = a.C0 + a.C1, nrow_t = NA * g.spt;
+    for (int i = tid; i < nrow_t * cin_t; i += NTHR) {
+      const int row = i / cin_t, c = i - row * cin_t;
+      const int b = ((g.spt == 1 ? row : (row >> 2)) ? tb0_[1] : tb0_[0]) + (g.spt == 1 ? 0 : (row & 3));
+      float2 o = {0.f, 0.f};
+      if (b < a.B) {
+        const float2 e = *reinterpret_cast<const float2*>(a.ab + ((size_t)b * cin_t + c) * 2);
+        o.x = HX_SA * e.x, o.y = HX_SA * e.y;
+      }
+      *reinterpret_cast<float2*>(sTab + (size_t)i * 2) = o;
+    }
+  }
+  if (has_tab)  // the all-zero row of the padding items
     for (int i = tid; i < 2 * (a.C0 + a.C1); i += NTHR) sTab[nrows_tab * (a.C0 + a.C1) * 2 + i] = 0.f;
   if (tid < ntot) {  // chunk descriptors: which tensor a chunk comes from (input / concat partner / 1x1-skip sources)
     const bool skip = tid >= nmain;
@@ -481,7 +497,7 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, (RGFM_HX2P_QEXP
   PPROF_T(tkc);
   __syncthreads();  // the scale/shift table and the chunk descriptors are complete
   PPROF_T(tkd);
-  const bool gn_on = a.gn_stats0 != nullptr;
+  const bool gn_on = has_tab;
   // ---- pipeline fill: halo of chunk 0 and weights of unit 0 in LDS, raw halo of chunk 1 and weights of unit 1 in registers
   {
     const hx_u32x4 d0 = chunk_desc(0);
@@ -828,6 +844,19 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, (RGFM_HX2P_QEXP
   auto epilogue = [&](auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
     unsigned vmask[2] = {0u, 0u};
+    if (a.ep_scale) {  // folded eval-mode BatchNorm (+ SiLU) of the ratio estimators' encoders, as conv_mfma.hip
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float es = a.ep_scale[n0 + nt * 32 + l31], eh = a.ep_shift[n0 + nt * 32 + l31];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[mt][nt][r] * es + eh;
+            acc[mt][nt][r] = a.ep_nosilu ? v : silu_f(v);
+          }
+      }
+    }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -922,7 +951,7 @@ static size_t hx2p_lds_bytes(const ConvArgs& a, int cfg) {
   const int nt = (cfg == HX2P_PAIRN_HALF || (RGFM_HX2P_QEXP && g_hx2p_q && cfg == HX2P_PAIRN && a.Cout == 64)) ? 1 : ((a.Cout % 64 == 0) ? 2 : 1);
   const int na = cfg == HX2P_TWO_TILES ? 2 : 1, nbt = 32 * nt * ((cfg == HX2P_PAIRN || cfg == HX2P_PAIRN_HALF) ? 2 : 1);
   size_t bytes = (size_t)2 * (na * hx2p_halo(a) + 1) * HRW + (size_t)2 * 3 * nbt * HRW;  // two halo buffers (+ pad record) + two weight units
-  if (a.gn_stats0) bytes += (size_t)(na * a.g.spt + 1) * (a.C0 + a.C1) * 2 * sizeof(float);  // scale/shift table + the zero row
+  if (a.gn_stats0 || a.ab) bytes += (size_t)(na * a.g.spt + 1) * (a.C0 + a.C1) * 2 * sizeof(float);  // scale/shift table + the zero row
   bytes += (size_t)(a.C0 + a.C1 + (a.res_mode == 2 ? a.R0 + a.R1 : 0));                    // 16 bytes per 16-channel chunk: descriptors
   return bytes;
 }
@@ -956,7 +985,6 @@ static int hx2p_cfg(const ConvArgs& a) {
 // the pipelined kernel takes: stride-1 / upsampling convs whose input norm (if any) is the consumer-side one
 bool conv_hx2p_supported(const ConvArgs& a, int mode) {
   if (mode != CONV_S1 && mode != CONV_UP2) return false;
-  if (a.ab && !a.gn_stats0) return false;
   if (!conv_hx2_supported(a, mode)) return false;
   if (a.gn_stats0 && !conv_hx2_gn_supported(a, mode)) return false;
   return hx2p_halo(a) <= 448 && hx2p_lds_bytes(a, hx2p_cfg(a)) <= 160 * 1024;

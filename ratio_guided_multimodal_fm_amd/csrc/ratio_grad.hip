@@ -52,8 +52,17 @@ void launch_fill_ab_identity(float* ab, size_t n_pairs, hipStream_t s) {
   hipLaunchKernelGGL(fill_ab_kernel, dim3(256), dim3(256), 0, s, ab, n_pairs);
 }
 
+// sigmoid by v_exp_f32 + v_rcp_f32 (~1 ulp each; the IEEE expf + division of the first version made this kernel
+// VALU-bound at 1.2 TB/s: ~50 instructions per sigmoid, 32 sigmoids per thread in the pooled modes); silu and its
+// derivative share it: silu(z) = z s, silu'(z) = s (1 + z (1 - s))
+__device__ __forceinline__ float sigmoid_fast(float v) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));
+}
+
 // one thread per (sample, output-side pixel group, 4 channels)
-__global__ void grad_act_kernel(const float* g, const float* z, const float* scale, float* gz, int B, int S, int C, int mode) {
+__global__ __launch_bounds__(256) void grad_act_kernel(const float* __restrict__ g, const float* __restrict__ z,
+                                                       const float* __restrict__ scale, float* __restrict__ gz, int B, int S,
+                                                       int C, int mode) {
   const int C4 = C / 4;
   if (mode == 1 || mode == 3) {
     const int So = S / 2;
@@ -75,7 +84,7 @@ __global__ void grad_act_kernel(const float* g, const float* z, const float* sca
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         off[k] = ((size_t)(b * S + 2 * oy + (k >> 1)) * S + 2 * ox + (k & 1)) * C + c4 * 4;
-        zv[k] = *reinterpret_cast<const f32x4*>(z + off[k]);
+        zv[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(z + off[k]));
       }
       f32x4 o[4];
 #pragma unroll
@@ -83,19 +92,20 @@ __global__ void grad_act_kernel(const float* g, const float* z, const float* sca
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         // F.max_pool2d backward: the first maximum of silu(z) in scan order (ky, kx), strict '>'
-        int best = 0;
-        float bv = silu_f(zv[0][e]);
+        float sg[4], sv[4];
 #pragma unroll
-        for (int k = 1; k < 4; ++k) {
-          const float v = silu_f(zv[k][e]);
-          if (v > bv) bv = v, best = k;
-        }
+        for (int k = 0; k < 4; ++k) sg[k] = sigmoid_fast(zv[k][e]), sv[k] = zv[k][e] * sg[k];
+        int best = 0;
+        float bv = sv[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+          if (sv[k] > bv) bv = sv[k], best = k;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          if (k == best) o[k][e] = gv[e] * dsilu_g(zv[k][e]) * sc[e];
+          if (k == best) o[k][e] = gv[e] * (sg[k] * (1.0f + zv[k][e] * (1.0f - sg[k]))) * sc[e];
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(gz + off[k]) = o[k];
+      for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(o[k], reinterpret_cast<f32x4*>(gz + off[k]));
     }
   } else {
     const size_t total = (size_t)B * S * S * C4;
@@ -104,34 +114,46 @@ __global__ void grad_act_kernel(const float* g, const float* z, const float* sca
       const int c4 = i % C4;
       const size_t px = i / C4;
       const size_t b = px / ((size_t)S * S);
-      const f32x4 zv = *reinterpret_cast<const f32x4*>(z + px * C + c4 * 4);
+      const f32x4 zv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(z + px * C + c4 * 4));
       const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
       f32x4 gv;
       if (mode == 2) {
         gv = *reinterpret_cast<const f32x4*>(g + b * C + c4 * 4);
         gv = gv * inv;
       } else {
-        gv = *reinterpret_cast<const f32x4*>(g + px * C + c4 * 4);
+        gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + px * C + c4 * 4));
       }
       f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = gv[e] * dsilu_g(zv[e]) * sc[e];
+      for (int e = 0; e < 4; ++e) {
+        const float sg = sigmoid_fast(zv[e]);
+        o[e] = gv[e] * (sg * (1.0f + zv[e] * (1.0f - sg))) * sc[e];
+      }
       *reinterpret_cast<f32x4*>(gz + px * C + c4 * 4) = o;
     }
   }
 }
 void launch_grad_act(const float* g, const float* z, const float* scale, float* gz, int B, int S, int C, int mode, hipStream_t s) {
   const size_t total = (size_t)B * ((mode == 1 || mode == 3) ? (S / 2) * (S / 2) : S * S) * (C / 4);
-  const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  const unsigned blocks = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
   hipLaunchKernelGGL(grad_act_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, g, z, scale, gz, B, S, C, mode);
 }
 
-// gimg[b][c][y][x] = sum_{co, ky, kx} w[co][c][ky][kx] gz[b][y - ky + 1][x - kx + 1][co]; one wave per output
-// pixel, lanes over co (Co = 32 or 64), the CIMG x 9 partial sums reduced across the wave
+// gimg[b][c][y][x] = sum_{co, ky, kx} w[co][c][ky][kx] gz[b][y - ky + 1][x - kx + 1][co].  One thread per output
+// pixel (all CIMG image channels); the weights sit in LDS as [tap][co][CIMG] so that a tap's four output channels are
+// wave-uniform broadcast reads; gz is read as 16-byte pieces of a neighbour pixel's channel vector (the nine
+// neighbours of adjacent pixels overlap: L1 / L2 serve them).  The first version (one WAVE per pixel, lanes over co,
+// a wave reduction per image channel) ran at 2 TFLOP/s: 0.89 ms for the SVHN encoder at B = 512.
 template <int CIMG>
-__global__ __launch_bounds__(256) void conv_bwd_img_kernel(const float* gz, const float* w, float* gimg, int B, int S, int Co) {
-  const int lane = threadIdx.x & 63;
-  const size_t px = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+__global__ __launch_bounds__(256) void conv_bwd_img_kernel(const float* __restrict__ gz, const float* __restrict__ w,
+                                                           float* __restrict__ gimg, int B, int S, int Co) {
+  extern __shared__ __attribute__((aligned(16))) float swt[];  // [9][Co][CIMG padded to 4]
+  for (int i = threadIdx.x; i < 9 * Co * 4; i += 256) {
+    const int c = i & 3, co = (i >> 2) % Co, k = (i >> 2) / Co;
+    swt[i] = c < CIMG ? w[((size_t)co * CIMG + c) * 9 + k] : 0.f;
+  }
+  __syncthreads();
+  const size_t px = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (px >= (size_t)B * S * S) return;
   const int x = px % S;
   const int y = (px / S) % S;
@@ -139,33 +161,35 @@ __global__ __launch_bounds__(256) void conv_bwd_img_kernel(const float* gz, cons
   float acc[CIMG];
 #pragma unroll
   for (int c = 0; c < CIMG; ++c) acc[c] = 0.f;
-  for (int co = lane; co < Co; co += 64) {
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int yo = y - ky + 1;
-      if (yo < 0 || yo >= S) continue;
+  for (int ky = 0; ky < 3; ++ky) {
+    const int yo = y - ky + 1;
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int xo = x - kx + 1;
-        if (xo < 0 || xo >= S) continue;
-        const float gv = gz[((b * S + yo) * S + xo) * Co + co];
+    for (int kx = 0; kx < 3; ++kx) {
+      const int xo = x - kx + 1;
+      if (yo < 0 || yo >= S || xo < 0 || xo >= S) continue;
+      const f32x4* gp = reinterpret_cast<const f32x4*>(gz + ((b * S + yo) * S + xo) * Co);
+      const f32x4* wp = reinterpret_cast<const f32x4*>(swt + (size_t)(ky * 3 + kx) * Co * 4);
+#pragma unroll 4
+      for (int c4 = 0; c4 < Co / 4; ++c4) {
+        const f32x4 gv = gp[c4];
 #pragma unroll
-        for (int c = 0; c < CIMG; ++c) acc[c] += w[((size_t)co * CIMG + c) * 9 + ky * 3 + kx] * gv;
+        for (int e = 0; e < 4; ++e) {
+          const f32x4 wv = wp[c4 * 4 + e];
+#pragma unroll
+          for (int c = 0; c < CIMG; ++c) acc[c] = fmaf(wv[c], gv[e], acc[c]);
+        }
       }
     }
   }
 #pragma unroll
-  for (int c = 0; c < CIMG; ++c) {
-    float v = acc[c];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if (lane == 0) gimg[((b * CIMG + c) * S + y) * S + x] = v;
-  }
+  for (int c = 0; c < CIMG; ++c) gimg[((b * CIMG + c) * S + y) * S + x] = acc[c];
 }
 void launch_conv_bwd_img(const float* gz, const float* w, float* gimg, int B, int S, int Co, int cimg, hipStream_t s) {
-  const unsigned blocks = (unsigned)(((size_t)B * S * S + 3) / 4);
-  if (cimg == 1) hipLaunchKernelGGL(conv_bwd_img_kernel<1>, dim3(blocks), dim3(256), 0, s, gz, w, gimg, B, S, Co);
-  else hipLaunchKernelGGL(conv_bwd_img_kernel<3>, dim3(blocks), dim3(256), 0, s, gz, w, gimg, B, S, Co);
+  const unsigned blocks = (unsigned)(((size_t)B * S * S + 255) / 256);
+  const size_t lds = (size_t)9 * Co * 4 * sizeof(float);
+  if (cimg == 1) hipLaunchKernelGGL(conv_bwd_img_kernel<1>, dim3(blocks), dim3(256), lds, s, gz, w, gimg, B, S, Co);
+  else hipLaunchKernelGGL(conv_bwd_img_kernel<3>, dim3(blocks), dim3(256), lds, s, gz, w, gimg, B, S, Co);
 }
 
 __device__ __forceinline__ float wsum_g(float v) {

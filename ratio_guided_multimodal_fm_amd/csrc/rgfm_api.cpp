@@ -1288,6 +1288,12 @@ struct rgfm_ratio {
   // gradient path (kind RGFM_RATIO_MNIST_SVHN): transposed weights, built at create time
   float* gradw = nullptr;  // [packed W^T of every conv after the first | fc W^T | dense W^T | zeros]
   size_t n_gradw = 0, g_zeros = 0;
+  // the encoders' 3x3 convs once more as two scaled fp16 planes (conv_mfma_hx2*.hip): the forward half of the
+  // gradient-guided sampler's per-step ratio pass runs on the default arithmetic of the U-Nets it guides
+  unsigned short* packedh = nullptr;
+  float* hq = nullptr;
+  size_t n_packedh = 0;
+  int n_hq = 0;
   size_t n_params = 0, n_packed = 0, n_bn = 0;
   struct Conv {
     size_t wt_pk = 0;  // packed transposed weights (offset into gradw), convs after the first
@@ -1333,6 +1339,7 @@ size_t plan_ratio(const rgfm_ratio_desc& d, rgfm_ratio* h) {
       cv.w.b = c.take(chans[i]);
       if (i > 0) cv.w.w_pk = pk.take((size_t)chans[i] * ci * 9);
       if (i > 0) cv.wt_pk = gw.take((size_t)chans[i] * ci * 9);
+      if (i > 0 && h) cv.w.w_hx2 = h->n_packedh, h->n_packedh += (size_t)chans[i] * ci * 9 * 2, cv.w.hq = h->n_hq++;
       cv.nw = c.take(chans[i]);
       cv.nb = c.take(chans[i]);
       if (batchnorm) {
@@ -1550,6 +1557,16 @@ extern "C" int rgfm_ratio_create(const rgfm_ratio_desc* desc, const float* param
       return bail(RGFM_EHIP, "building the transposed weights failed");
     }
     (void)hipFree(tmp);
+    if (hipMalloc(&h->packedh, (h->n_packedh + 8) * sizeof(unsigned short)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(packedh)");
+    if (hipMalloc(&h->hq, ((size_t)h->n_hq * 4 + 4) * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(hq)");
+    std::vector<ConvW*> all;
+    for (auto* e : {&h->ex, &h->ey})
+      for (size_t i = 1; i < e->convs.size(); ++i) {
+        ConvW& w = e->convs[i].w;
+        launch_pack_conv_hx2(h->params + w.w_raw, h->packedh + w.w_hx2, h->hq + 4 * w.hq, w.cout, w.cin, 9, CONV_S1, s);
+        all.push_back(&w);
+      }
+    if (read_hx_flags(h->hq, h->n_hq, all, s) != RGFM_OK) return bail(RGFM_EHIP, "reading the fp16 scale records failed");
   }
   *out = h;
   return RGFM_OK;
@@ -1560,6 +1577,8 @@ extern "C" void rgfm_ratio_destroy(rgfm_ratio* h) {
   if (h->params) (void)hipFree(h->params);
   if (h->packed) (void)hipFree(h->packed);
   if (h->bn) (void)hipFree(h->bn);
+  if (h->packedh) (void)hipFree(h->packedh);
+  if (h->hq) (void)hipFree(h->hq);
   if (h->gradw) (void)hipFree(h->gradw);
   delete h;
 }
@@ -1603,6 +1622,10 @@ struct RatioGradRun {
   Bump* ws;
   hipStream_t s;
   bool dry;
+  // the range-flag word of the U-Net handle whose sampler loop this pass belongs to, or null (stand-alone gradient:
+  // exact fp32 convs).  With it the encoders' forward convs follow that handle's conv arithmetic (g_modes, set by the
+  // caller's ModeScope) and raise ITS flag, so that the sampler's range guard and fallback cover them.
+  unsigned* flag = nullptr;
   float* ab1 = nullptr;  // [n][256][2] identity scale/shift: "SiLU on load"
 
   struct Kept {
@@ -1636,7 +1659,12 @@ struct RatioGradRun {
           c.ep_scale = h->bn + cv.bn_scale, c.ep_shift = h->bn + cv.bn_shift, c.ep_nosilu = 1;
           c.out = z, c.stats_out = nullptr, c.B = n, c.Cout = cv.w.cout, c.g = g;
           c.halo_px = g.spt * (g.th + 2) * (g.W + 2);
-          launch_conv_mfma(c, CONV_S1, s);
+          if (flag && g_modes.conv == CONV_ARITH_HX2 && cv.w.hx_ok) {
+            c.wpkh = h->packedh + cv.w.w_hx2, c.hq = h->hq + 4 * cv.w.hq, c.range_flag = flag;
+            launch_conv(c, CONV_S1, s);  // (fp16 two-plane conv with the BatchNorm epilogue; fp32 MFMA when unsupported)
+          } else {
+            launch_conv_mfma(c, CONV_S1, s);
+          }
         }
       }
       kept.push_back({z, cv.w.cout, S, cv.pool_after});
@@ -1842,6 +1870,8 @@ extern "C" int rgfm_sample_pair_grad(rgfm_unet* hx, rgfm_unet* hy, rgfm_ratio* h
     {
       b.off = mark_r;
       RatioGradRun r{hr, batch, &b, s, false};
+      r.flag = hx->range_flag;
+      ModeScope ratio_mode(hx->conv_mode);  // (the estimator's forward convs follow the x net's handle)
       r.run(x_inout, y_inout, gx, gy, nullptr);
     }
     if (overlap) HIP_TRY(hipStreamWaitEvent(s, ds->join, 0));
