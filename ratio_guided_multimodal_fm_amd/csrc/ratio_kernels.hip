@@ -8,7 +8,8 @@
 namespace rgfm {
 
 // F.max_pool2d(., 2) (floor) on NHWC, with an optional GroupNorm-apply + SiLU
-// (a*x+b from gn_finalize) in front for the GroupNorm encoder
+// (a*x+b from gn_finalize) in front for the GroupNorm encoder; SiLU by v_exp_f32 + v_rcp_f32 (~1 ulp each, as on the
+// convs' load path and in grad_act_kernel's routing: the IEEE form made these kernels VALU-bound)
 // (ratio_estimator.py:75-82: silu(gn(conv)) then pool).
 __global__ void pool2_kernel(const float* in, const float* ab, float* out, int B, int H, int W, int C) {
   const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
@@ -30,10 +31,10 @@ __global__ void pool2_kernel(const float* in, const float* ab, float* out, int B
       for (int dx = 0; dx < 2; ++dx) {
         f32x4 v = *reinterpret_cast<const f32x4*>(in + ((size_t)(b * H + 2 * oy + dy) * W + 2 * ox + dx) * C + c4 * 4);
         if (ab) {
-          v.x = silu_f(e0.x * v.x + e0.y);
-          v.y = silu_f(e0.z * v.y + e0.w);
-          v.z = silu_f(e1.x * v.z + e1.y);
-          v.w = silu_f(e1.z * v.w + e1.w);
+          v.x = silu_fast(e0.x * v.x + e0.y);
+          v.y = silu_fast(e0.z * v.y + e0.w);
+          v.z = silu_fast(e1.x * v.z + e1.y);
+          v.w = silu_fast(e1.z * v.w + e1.w);
         }
         m.x = fmaxf(m.x, v.x), m.y = fmaxf(m.y, v.y), m.z = fmaxf(m.z, v.z), m.w = fmaxf(m.w, v.w);
       }
@@ -61,7 +62,7 @@ __global__ void avgpool_kernel(const float* in, const float* ab, float* out, int
     float s = 0.f;
     for (int p = 0; p < HW; ++p) {
       float v = in[(b * HW + p) * C + c];
-      if (ab) v = silu_f(sa * v + sb);
+      if (ab) v = silu_fast(sa * v + sb);
       s += v;
     }
     out[i] = s / (float)HW;
