@@ -68,15 +68,26 @@ __device__ long long g_hx2p_trace[2][64][9];  // block 3, waves 0 and 4: per uni
 // under-filled launches, where one tile per workgroup means twice the workgroups.
 // HX2P_PAIRN_HALF: as HX2P_PAIRN with 32-channel groups (NT = 1): one tile x 64 of a 128-channel weight block, twice the
 // workgroups -- for launches that would otherwise leave CUs without a workgroup (the 8x8 level, small batches).
-enum { HX2P_TWO_TILES = 0, HX2P_PAIRN = 1, HX2P_FOUR_WAVES = 2, HX2P_PAIRN_HALF = 3 };
+// HX2P_PAIRN_HALF_C (round 3): HX2P_PAIRN_HALF with CHUNK-sized units -- all nine taps of a 16-channel chunk between two
+// barriers, the weight buffers hold a whole chunk (2 x 37 KB: there is room where this cut runs, one under-filled
+// workgroup per CU).  Such launches are one round of <= 256 workgroups whose time is the serial chain of a unit
+// (barrier, table read, transform, store, barrier) times the number of units: a third of the units, three times the
+// MFMAs behind each chain.  Same per-element summation order: bit-identical results.  MEASURED (tools/kbench
+// scripts/q12.sh, -DRGFM_HX2P_CHUNK_EXP): 2 ... 9 % SLOWER than the unit-sized form on every such launch (8x8 at B = 512 /
+// 256, 16x16 at B = 128 / 64) -- their time is proportional to the work in a unit, not to the number of barriers; built
+// for kbench only.
+enum { HX2P_TWO_TILES = 0, HX2P_PAIRN = 1, HX2P_FOUR_WAVES = 2, HX2P_PAIRN_HALF = 3, HX2P_PAIRN_HALF_C = 4 };
 
 template <int NT, int MODE, int CFG>
 #ifndef RGFM_HX2P_QEXP
 #define RGFM_HX2P_QEXP 0  // (kbench experiment: NT = 1 one-tile x 64-channel workgroups at four waves per SIMD, two workgroups per CU)
 #endif
 __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, (RGFM_HX2P_QEXP && NT == 1 && CFG == HX2P_PAIRN) ? 4 : 2) void conv_mfma_hx2p_kernel(const ConvArgs a, const int num_tiles) {
-  constexpr bool PAIRN = CFG == HX2P_PAIRN || CFG == HX2P_PAIRN_HALF;
-  constexpr bool HALF = CFG == HX2P_PAIRN_HALF;  // the packed weight blocks hold 128 channels, this workgroup takes 64 of them
+  constexpr bool CW = CFG == HX2P_PAIRN_HALF_C;  // chunk-sized units
+  constexpr bool PAIRN = CFG == HX2P_PAIRN || CFG == HX2P_PAIRN_HALF || CW;
+  constexpr bool HALF = CFG == HX2P_PAIRN_HALF || CW;  // the packed weight blocks hold 128 channels, this workgroup takes 64 of them
+  constexpr int TPU = CW ? 9 : 3;              // taps per unit
+  constexpr int UPC = 9 / TPU;                 // units per main chunk
   static_assert(!HALF || NT == 1, "HX2P_PAIRN_HALF: 2 groups x 32 channels");
   constexpr bool W4 = CFG == HX2P_FOUR_WAVES;
   constexpr int NTHR = W4 ? 256 : 512;
@@ -87,7 +98,7 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, (RGFM_HX2P_QEXP
   constexpr int NBLK = 32 * NT;                // channels per group
   constexpr int NBT = NBLK * NG;               // channels per block
   constexpr int TAPB = NBT * HRW;              // bytes of one tap's weight slab
-  constexpr int UB = 3 * TAPB;                 // weights of one unit (3 taps)
+  constexpr int UB = TPU * TAPB;               // weights of one unit
   constexpr int NB = (UB / 16 + NTHR - 1) / NTHR;    // 16-byte weight items per thread and unit
   constexpr int MAXIT = (NA * 448 * 4 + NTHR - 1) / NTHR;  // halo items (pixel, 4 channels) per thread and chunk
   extern __shared__ __attribute__((aligned(16))) char smemp[];
@@ -332,11 +343,11 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, (RGFM_HX2P_QEXP
   const int nmain = cin / KC;                                   // 16-channel chunks of the input
   const int nskip = (a.res_mode == 2) ? (a.R0 + a.R1) / KC : 0;  // 1x1-skip chunks (one tap each)
   const int ntot = nmain + nskip;
-  const int G = 3 * nmain + nskip;                              // units
+  const int G = UPC * nmain + nskip;                            // units
   // packed weights: [channel block][chunk][tap] slabs of TAPS bytes (TAPS = TAPB, or 2 TAPB when this workgroup takes
   // half of a 128-channel block: then a tap's slab holds this half at offset whalf)
   constexpr int TAPS = HALF ? 2 * TAPB : TAPB;
-  constexpr int UBS = 3 * TAPS;
+  constexpr int UBS = TPU * TAPS;
   const int wblk = HALF ? (int)blockIdx.y >> 1 : (int)blockIdx.y;
   const int whalf = HALF ? ((int)blockIdx.y & 1) * TAPB : 0;
   const char* wpk = reinterpret_cast<const char*>(a.wpkh) + (size_t)wblk * nmain * 9 * TAPS + whalf;
@@ -395,8 +406,8 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, (RGFM_HX2P_QEXP
   };
   // weights of unit gg: the packed image is the LDS byte image, a linear 16-byte copy (a skip unit is one tap)
   auto issue_b = [&](int gg) {
-    const bool main = gg < 3 * nmain;
-    const char* src = main ? wpk + (size_t)gg * UBS : wsk + (size_t)(gg - 3 * nmain) * TAPS;
+    const bool main = gg < UPC * nmain;
+    const char* src = main ? wpk + (size_t)gg * UBS : wsk + (size_t)(gg - UPC * nmain) * TAPS;
     const int nit = main ? UB / 16 : TAPB / 16;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -405,7 +416,7 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, (RGFM_HX2P_QEXP
     }
   };
   auto commit_b = [&](int gg) {
-    const int nit = gg < 3 * nmain ? UB / 16 : TAPB / 16;
+    const int nit = gg < UPC * nmain ? UB / 16 : TAPB / 16;
     char* dst = sB + (gg & 1) * UB;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -789,8 +800,25 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, (RGFM_HX2P_QEXP
     ++gidx;
   };
   int c0 = 0;
+  if constexpr (CW) {
+    // chunk-sized units: stage everything of chunk c + 1 (all halo items, nine taps of weights), multiply chunk c's nine
+    // taps, ONE barrier; the two waves of a SIMD at opposite ends as in unit()
+#pragma unroll 1
+    for (; c0 < nmain; ++c0) {
+      const char* sAc = smemp + (c0 & 1) * abytes;
+      const char* sBu = sB + (gidx & 1) * UB;
+      if (role == 0) stage(c0, UA{}, gidx);
+      tap(sAc, sBu, K0{}), tap(sAc, sBu + TAPB, K1{}), tap(sAc, sBu + 2 * TAPB, K2{});
+      tap(sAc + WR * HRW, sBu + 3 * TAPB, K0{}), tap(sAc + WR * HRW, sBu + 4 * TAPB, K1{}), tap(sAc + WR * HRW, sBu + 5 * TAPB, K2{});
+      tap(sAc + 2 * WR * HRW, sBu + 6 * TAPB, K0{}), tap(sAc + 2 * WR * HRW, sBu + 7 * TAPB, K1{}),
+          tap(sAc + 2 * WR * HRW, sBu + 8 * TAPB, K2{});
+      if (role != 0) stage(c0, UA{}, gidx);
+      if (gidx != G - 1) __syncthreads();
+      ++gidx;
+    }
+  }
 #if RGFM_HX2P_FAST
-  if (!(RGFM_HX2P_QEXP && NT == 1 && CFG == HX2P_PAIRN) && gn_on && nitems >= 3) {
+  if (!CW && !(RGFM_HX2P_QEXP && NT == 1 && CFG == HX2P_PAIRN) && gn_on && nitems >= 3) {
 #pragma unroll 1
     for (; c0 < nmain - 1; ++c0) {
       unit_fast(c0, U0{});
@@ -948,9 +976,11 @@ static int hx2p_halo(const ConvArgs& a) { return a.g.spt * (a.g.th + 2) * (a.g.W
 static int g_hx2p_q = 0;  // RGFM_HX2P_QEXP builds: Cout == 64 layers as NT = 1 HX2P_PAIRN workgroups
 void conv_hx2p_set_q(int v) { g_hx2p_q = v; }
 static size_t hx2p_lds_bytes(const ConvArgs& a, int cfg) {
-  const int nt = (cfg == HX2P_PAIRN_HALF || (RGFM_HX2P_QEXP && g_hx2p_q && cfg == HX2P_PAIRN && a.Cout == 64)) ? 1 : ((a.Cout % 64 == 0) ? 2 : 1);
-  const int na = cfg == HX2P_TWO_TILES ? 2 : 1, nbt = 32 * nt * ((cfg == HX2P_PAIRN || cfg == HX2P_PAIRN_HALF) ? 2 : 1);
-  size_t bytes = (size_t)2 * (na * hx2p_halo(a) + 1) * HRW + (size_t)2 * 3 * nbt * HRW;  // two halo buffers (+ pad record) + two weight units
+  const bool halfc = cfg == HX2P_PAIRN_HALF || cfg == HX2P_PAIRN_HALF_C;
+  const int nt = (halfc || (RGFM_HX2P_QEXP && g_hx2p_q && cfg == HX2P_PAIRN && a.Cout == 64)) ? 1 : ((a.Cout % 64 == 0) ? 2 : 1);
+  const int na = cfg == HX2P_TWO_TILES ? 2 : 1, nbt = 32 * nt * ((cfg == HX2P_PAIRN || halfc) ? 2 : 1);
+  const int tpu = cfg == HX2P_PAIRN_HALF_C ? 9 : 3;
+  size_t bytes = (size_t)2 * (na * hx2p_halo(a) + 1) * HRW + (size_t)2 * tpu * nbt * HRW;  // two halo buffers (+ pad record) + two weight units
   if (a.gn_stats0 || a.ab) bytes += (size_t)(na * a.g.spt + 1) * (a.C0 + a.C1) * 2 * sizeof(float);  // scale/shift table + the zero row
   bytes += (size_t)(a.C0 + a.C1 + (a.res_mode == 2 ? a.R0 + a.R1 : 0));                    // 16 bytes per 16-channel chunk: descriptors
   return bytes;
@@ -968,6 +998,18 @@ void conv_hx2p_set_w4(int v) { g_hx2p_w4 = v; }
 // launches with fewer workgroups than this are cut finer (0: never); the CU count
 static int g_hx2p_half = 256;
 void conv_hx2p_set_half(int v) { g_hx2p_half = v; }
+#ifdef RGFM_HX2P_CHUNK_EXP
+static int g_hx2p_chunk = 1;  // 0: no chunk-sized units (HX2P_PAIRN_HALF_C) -- kbench A/B
+#else
+static int g_hx2p_chunk = 0;  // (the instantiations exist in kbench builds only)
+#endif
+void conv_hx2p_set_chunk(int v) {
+#ifdef RGFM_HX2P_CHUNK_EXP
+  g_hx2p_chunk = v;
+#else
+  (void)v;
+#endif
+}
 static int hx2p_cfg(const ConvArgs& a) {
   const bool fits = hx2p_lds_bytes(a, HX2P_FOUR_WAVES) <= 80 * 1024;  // two workgroups per CU
   if (g_hx2p_w4 == 2 && fits) return HX2P_FOUR_WAVES;
@@ -979,7 +1021,9 @@ static int hx2p_cfg(const ConvArgs& a) {
     return (g_hx2p_half && wgs < g_hx2p_half) ? HX2P_FOUR_WAVES : HX2P_TWO_TILES;
   }
   const int wgs = tiles * (a.Cout / 128);
-  return (g_hx2p_half && wgs < g_hx2p_half) ? HX2P_PAIRN_HALF : HX2P_PAIRN;
+  if (!(g_hx2p_half && wgs < g_hx2p_half)) return HX2P_PAIRN;
+  // chunk-sized units where their weight buffers fit beside the halo (the 8x8 level; 16x16 at small batches)
+  return (g_hx2p_chunk && hx2p_lds_bytes(a, HX2P_PAIRN_HALF_C) <= 160 * 1024) ? HX2P_PAIRN_HALF_C : HX2P_PAIRN_HALF;
 }
 
 // the pipelined kernel takes: stride-1 / upsampling convs whose input norm (if any) is the consumer-side one
@@ -1001,6 +1045,9 @@ int conv_hx2p_init() {
   RAISEP(1, CONV_S1, HX2P_PAIRN); RAISEP(1, CONV_UP2, HX2P_PAIRN);
 #endif
   RAISEP(1, CONV_S1, HX2P_PAIRN_HALF); RAISEP(1, CONV_UP2, HX2P_PAIRN_HALF);
+#ifdef RGFM_HX2P_CHUNK_EXP
+  RAISEP(1, CONV_S1, HX2P_PAIRN_HALF_C); RAISEP(1, CONV_UP2, HX2P_PAIRN_HALF_C);
+#endif
   RAISEP(1, CONV_S1, HX2P_FOUR_WAVES); RAISEP(1, CONV_UP2, HX2P_FOUR_WAVES);
   RAISEP(2, CONV_S1, HX2P_FOUR_WAVES); RAISEP(2, CONV_UP2, HX2P_FOUR_WAVES);
 #undef RAISEP
@@ -1013,9 +1060,9 @@ void launch_conv_hx2p(const ConvArgs& a_in, int mode, hipStream_t s) {
   const int nt = (a.Cout % 64 == 0) ? 2 : 1;
   const int tiles = geom_num_tiles(a.g, a.B);
   const int cfg = hx2p_cfg(a);
-  if (cfg == HX2P_PAIRN_HALF) a.fin_expected *= 2;  // (producer-side finalize: twice the 4-wave groups along the channels arrive)
+  if (cfg == HX2P_PAIRN_HALF || cfg == HX2P_PAIRN_HALF_C) a.fin_expected *= 2;  // (producer-side finalize: twice the 4-wave groups along the channels arrive)
   dim3 grid(cfg == HX2P_TWO_TILES ? (tiles + 1) / 2 : tiles,
-            cfg == HX2P_PAIRN ? a.Cout / 128 : (cfg == HX2P_PAIRN_HALF ? a.Cout / 64 : a.Cout / (32 * nt)), 1);
+            cfg == HX2P_PAIRN ? a.Cout / 128 : ((cfg == HX2P_PAIRN_HALF || cfg == HX2P_PAIRN_HALF_C) ? a.Cout / 64 : a.Cout / (32 * nt)), 1);
   const size_t lds = hx2p_lds_bytes(a, cfg);
 #define LAUNCHP(NTV, M, P) hipLaunchKernelGGL((conv_mfma_hx2p_kernel<NTV, M, P>), grid, dim3(P == HX2P_FOUR_WAVES ? 256 : 512), lds, s, a, tiles)
 #define LAUNCHM(NTV, P)                           \
@@ -1031,6 +1078,9 @@ void launch_conv_hx2p(const ConvArgs& a_in, int mode, hipStream_t s) {
 #endif
   if (cfg == HX2P_PAIRN) LAUNCHM(2, HX2P_PAIRN);
   else if (cfg == HX2P_PAIRN_HALF) LAUNCHM(1, HX2P_PAIRN_HALF);
+#ifdef RGFM_HX2P_CHUNK_EXP
+  else if (cfg == HX2P_PAIRN_HALF_C) LAUNCHM(1, HX2P_PAIRN_HALF_C);
+#endif
   else if (cfg == HX2P_FOUR_WAVES) {
     if (nt == 2) LAUNCHM(2, HX2P_FOUR_WAVES);
     else LAUNCHM(1, HX2P_FOUR_WAVES);

@@ -219,6 +219,7 @@ void launch_conv_hx2(const ConvArgs& a, int mode, hipStream_t s);
 bool conv_hx2p_supported(const ConvArgs& a, int mode);
 int conv_hx2p_init();
 void conv_hx2p_set_half(int v);  // launches with fewer workgroups than this are cut finer (0: never; the CU count)
+void conv_hx2p_set_chunk(int v);  // 0: no chunk-sized units for the under-filled 64-channel cut (A/B)
 void conv_hx2p_set_w4(int v);  // tools/kbench A/B: 1 / 2 = four-wave workgroups forced, see conv_mfma_hx2p.hip
 void launch_conv_hx2p(const ConvArgs& a, int mode, hipStream_t s);
 // four-waves-per-SIMD version (conv_mfma_hx2q.hip: one tile x 64 channels at a time, two workgroups per CU, several

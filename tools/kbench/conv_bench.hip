@@ -71,6 +71,7 @@ int main(int argc, char** argv) {
   if (getenv("RGFM_HX2Q_CUT")) conv_hx2q_set_cut(atoi(getenv("RGFM_HX2Q_CUT")));
   if (getenv("RGFM_HX2P_W4")) conv_hx2p_set_w4(atoi(getenv("RGFM_HX2P_W4")));
   if (getenv("RGFM_HX2P_HALF")) conv_hx2p_set_half(atoi(getenv("RGFM_HX2P_HALF")));
+  if (getenv("RGFM_HX2P_CHUNK")) conv_hx2p_set_chunk(atoi(getenv("RGFM_HX2P_CHUNK")));
 #if RGFM_HX2P_QEXP
   if (getenv("RGFM_HX2P_Q")) conv_hx2p_set_q(atoi(getenv("RGFM_HX2P_Q")));
 #endif
