@@ -14,13 +14,30 @@ typedef unsigned hx_u32x2 __attribute__((ext_vector_type(2)));
 constexpr float HX_SA = 16.f;         // activation scale S_A
 constexpr float HX_LIMIT = 32768.f;   // |a'| at or above this raises the range flag
 
-// 2-way fp16 split of two (already scaled) floats: planes h, l as packed fp16 pairs (v_cvt_pk_f16_f32, RNE)
+// 2-way fp16 split of two (already scaled) floats: planes h, l as packed fp16 pairs.  h = v_cvt_pk_f16_f32 (RNE); the
+// remainder a - float(h) in ONE v_fma_mix_f32 per value (the fp16 half is an operand: no v_cvt_f32_f16, and no packed
+// v_pk_add_f32, which hipcc makes of the vector form and which is an anti-lever beside MFMAs); exact either way, so the
+// planes are bit for bit those of the conversion + subtraction form.  The staging path is VALU-issue-bound in the MFMA
+// shadow (tools/ubench/mfma_valu_overlap.hip: ~5.5 vector instructions per MFMA slot from the other waves of a SIMD):
+// every instruction per item counts.
 __device__ __forceinline__ void hsplit2(float a, float b, unsigned& ph, unsigned& pl) {
   hx_f32x2 v = {a, b};
   const f16x2 h = __builtin_convertvector(v, f16x2);
   ph = __builtin_bit_cast(unsigned, h);
-  v = v - __builtin_convertvector(h, hx_f32x2);
-  pl = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+  float la, lb;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(la) : "v"(ph), "v"(a));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(ph), "v"(b));
+  const hx_f32x2 lv = {la, lb};
+  pl = __builtin_bit_cast(unsigned, __builtin_convertvector(lv, f16x2));
+}
+
+// High side of the staging path: plane h = fp16(S_A a) reaches 32768 (fp16's top binade, where the remainder plane stops
+// being exact -- and 65520 rounds to inf) from |S_A a| >= 32760 (round to nearest even).  The running max is taken on
+// the fp32 values before the split: v_max3_f32 with |.| source modifiers, one instruction per two values.  A NaN is not
+// caught here and need not be: it propagates into every output it touches, as in the reference.
+constexpr float HX_BIG = 32760.f;
+__device__ __forceinline__ float hx_absmax3(float a, float b, float m) {
+  return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), m);
 }
 
 // S_A silu(z) from z' = S_A z (v_exp_f32 + v_rcp_f32 as silu_fast)

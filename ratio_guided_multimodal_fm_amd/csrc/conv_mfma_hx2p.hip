@@ -363,9 +363,7 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, (RGFM_HX2P_QEXP
     boff[j] = (it < UB / 16 ? it : it - UB / 16) * 16;
     soff[j] = HALF ? (boff[j] / TAPB) * TAPS + (boff[j] % TAPB) : boff[j];
   }
-  // range flag: the largest |fp16| (as a bit pattern, per 16-bit half) this thread has stored; >= 0x7800 is |a'| >= 32768
-  typedef unsigned short hx_u16x2 __attribute__((ext_vector_type(2)));
-  hx_u16x2 hmax = {0, 0};
+  float hmax = 0.f;  // range flag: the largest |S_A a| this thread has split (two v_max3_f32 per item)
   const int nitems = (NA * nA + NTHR - 1) / NTHR;  // items that exist for at least one thread (block-uniform)
 
   // raw fp32 fetch of item j of a chunk whose descriptor is d (chunk_desc)
@@ -396,9 +394,8 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, (RGFM_HX2P_QEXP
     unsigned h0, l0, h1, l1;
     hsplit2(v.x, v.y, h0, l0);
     hsplit2(v.z, v.w, h1, l1);
-    const unsigned m = 0x7fff7fffu;
-    hmax = __builtin_elementwise_max(hmax, __builtin_bit_cast(hx_u16x2, h0 & m));
-    hmax = __builtin_elementwise_max(hmax, __builtin_bit_cast(hx_u16x2, h1 & m));
+    hmax = hx_absmax3(v.x, v.y, hmax);
+    hmax = hx_absmax3(v.z, v.w, hmax);
     const hx_u32x2 ph = {h0, h1}, pl = {l0, l1};
     char* base = smemp + (ch & 1) * abytes;
     *reinterpret_cast<hx_u32x2*>(base + adst[j]) = ph;
@@ -860,7 +857,7 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, (RGFM_HX2P_QEXP
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc[mt][nt] * qinv;
-    if (hmax[0] >= 0x7800 || hmax[1] >= 0x7800) atomicOr(a.range_flag, 1u);  // (rare) |a'| >= 32768 (or inf / nan): the host re-runs on bx3
+    if (!(hmax < HX_BIG)) atomicOr(a.range_flag, 1u);  // (rare) plane h would be >= 32768 (or inf): the host re-runs on bx3
   }
 
   // ---------------------------------------------------------------- epilogue (as conv_mfma_pf_kernel)

@@ -218,8 +218,7 @@ __global__ __launch_bounds__(256 * NG, (NG == 2 && NT == 1) ? 4 : 2) void conv_m
   const char* const wsk = reinterpret_cast<const char*>(a.wskiph) + (size_t)wblk * nskip * TAPS + whalf;
   // this thread's two 16-byte weight items of a unit: 768 items in a main unit (three taps), 256 in a skip unit (one
   // tap); threads past the unit's end repeat an earlier item (same bytes to the same address)
-  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-  u16x2 hmax = {0, 0};
+  float hmax = 0.f;  // range flag: the largest |S_A a| this thread has split (two v_max3_f32 per item)
   f32x4 ra[NIT];
 
   // ---- the stream.  A position is (tile index inside the workgroup, chunk, sample, tile inside the sample); the
@@ -271,9 +270,8 @@ __global__ __launch_bounds__(256 * NG, (NG == 2 && NT == 1) ? 4 : 2) void conv_m
     unsigned h0, l0, h1, l1;
     hsplit2(o.x, o.y, h0, l0);
     hsplit2(o.z, o.w, h1, l1);
-    const unsigned m = 0x7fff7fffu;
-    hmax = __builtin_elementwise_max(hmax, __builtin_bit_cast(u16x2, h0 & m));
-    hmax = __builtin_elementwise_max(hmax, __builtin_bit_cast(u16x2, h1 & m));
+    hmax = hx_absmax3(o.x, o.y, hmax);
+    hmax = hx_absmax3(o.z, o.w, hmax);
     const hx_u32x2 ph = {h0, h1}, pl = {l0, l1};
     char* base = smq + (gcn & 1) * ABYTES;
     const int ad = (int)(meta[j] & 0xffffu);
@@ -622,7 +620,7 @@ __global__ __launch_bounds__(256 * NG, (NG == 2 && NT == 1) ? 4 : 2) void conv_m
 #undef wdma
 #endif
 #undef HX2Q_WDMA_WAIT
-  if (hmax[0] >= 0x7800 || hmax[1] >= 0x7800) atomicOr(a.range_flag, 1u);  // (rare) |a'| >= 32768 (or inf / nan)
+  if (!(hmax < HX_BIG)) atomicOr(a.range_flag, 1u);  // (rare) plane h would be >= 32768 (or inf)
 #ifdef RGFM_HX2Q_PROF
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   QPROF_T(tq7);

@@ -130,7 +130,7 @@ int main(int argc, char** argv) {
   int skipk = 0;
   if (res == 1) a.res0 = dev_rand((size_t)B * S * S * Cout, 1.f, 6), a.R0 = Cout;
   if (res == 2) {
-    const int R = Cin;  // 1x1 skip from an R-channel source at output resolution
+    const int R = getenv("RGFM_KB_R") ? atoi(getenv("RGFM_KB_R")) : Cin;  // 1x1 skip from an R-channel source at output resolution
     a.res0 = dev_rand((size_t)B * S * S * R, 1.f, 6), a.R0 = R;
     float* ws = dev_rand((size_t)Cout * R, 0.05f, 7);
     float* wsp;
