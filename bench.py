@@ -352,16 +352,29 @@ def main():
                            "operands, 2 waves per SIMD on every CU, 0.25 s (rgfm_ubench_mfma_f16); float4 copy of 1 GiB "
                            "(rgfm_ubench_hbm_copy, read + written bytes)"}
             hk = {}
+            # the guidance block is arithmetic-bound, not HBM-bound (its operands are L2-resident): guid_logp is 3 fp32
+            # operations per (row, MC sample, element) on the vector ALU (direct differences: SURVEY 7), guid_apply the
+            # [B, N] x [N, D] fp32-MFMA GEMM of the weighted sum -- priced against the fp32 peaks, not against HBM
+            bnd = args.batch_per_gpu * args.mc * (1024.0 + 3072.0)
+            arith_classes = {"guid_logp": ("valu_f32", 3.0 * bnd, PEAK_FP32_MFMA_TFLOPS),  # (packed fp32 VALU peak = fp32 MFMA peak)
+                             "guid_apply": ("mfma_f32", 2.0 * bnd, PEAK_FP32_MFMA_TFLOPS)}
             for name, (busy, tot, nl, by) in hbm_classes.items():
                 if nl > 0 and tot > 0:
                     gbs = by / (tot * 1e-3) / 1e9
                     hk[name] = {"launches": int(nl), "avg_launch_us": 1e3 * tot / nl, "algorithmic_gbs": gbs,
                                 "frac_nominal": gbs / PEAK_HBM_GBS,
                                 "frac_measured_copy": (gbs / ceilings["hbm_copy_gbs"]) if ceilings else None}
+                    if name in arith_classes:
+                        bound, fl, peak = arith_classes[name]
+                        tf = fl / (1e-3 * tot / nl) / 1e12
+                        hk[name].update({"bound": bound, "algorithmic_tflops": tf, "peak_tflops": peak, "frac_arith": tf / peak})
+                    else:
+                        hk[name]["bound"] = "hbm"
             if hk:
                 line["roofline"]["hbm_kernels"] = {
-                    "what": "HBM-bound kernels of the step: algorithmic bytes (SURVEY 8d: every tensor once) / sum of launch "
-                            "durations; peak 8000 GB/s nominal, and the float4 copy measured above",
+                    "what": "the kernels of a step that are not the implicit-GEMM convs: algorithmic bytes (SURVEY 8d: every "
+                            "tensor once) / sum of launch durations against 8000 GB/s nominal and the float4 copy measured "
+                            "above; the guidance block also against its arithmetic bound (\"bound\")",
                     "share_of_call": sum(v[1] for v in hbm_classes.values()) * 1e-3 / elapsed, **hk}
             if alt is not None:
                 line["roofline"]["exact_fp32_mode"] = alt

@@ -8,10 +8,11 @@
 //               (direct differences, no GEMM expansion: late-time weights are
 //               scaled by 1/sigma_t^2 ~ 8e3 and cancellation would flip near-ties)
 //   guid_apply: row-normalised importance weights (exact reference epsilon
-//               sequence), g = sum_i w_i (m_i - x)/(1 - t + eps), blend
-//               (1-gamma) v + gamma g, and optionally the Euler update.
-// Both are HBM/L2-bound elementwise-reduction kernels; the MC set (N x D) stays
-// L2-resident.
+//               sequence), g = sum_i w_i (m_i - x)/(1 - t + eps) as an fp32-MFMA
+//               GEMM [B,N] x [N,D], blend (1-gamma) v + gamma g, and optionally the
+//               Euler update.
+// guid_logp is a VALU-bound elementwise reduction, guid_apply a small fp32 GEMM; the MC set
+// (N x D) stays L2-resident.
 #include "rgfm_device.h"
 
 namespace rgfm {
@@ -19,7 +20,7 @@ namespace rgfm {
 constexpr int GD = 64;        // D-chunk
 constexpr int GLD = GD + 4;   // LDS row stride (floats): conflict-free b128 rows
 
-// Squared distances, sliced along D: block (bx, by, z) adds up slice z of one modality for a 32 x 32 tile of
+// Squared distances, sliced along D: block (bx, by, z) adds up slice z of one modality for a 32 x 64 tile of
 // (row, MC sample) pairs and writes the fp64 partial sum; guid_apply adds the slices (fp64 sums of fp32 chunk
 // partials are exact, so the slicing does not change a bit) -- 4x the workgroups of an unsliced launch at the
 // benchmark shape, where 16 x 8 tiles would leave half of the 256 CUs idle on a kernel that nothing overlaps.
@@ -33,13 +34,23 @@ __device__ __forceinline__ GuidanceArgs with_schedule(const GuidanceArgs& in) {
   return a;
 }
 
+// Thread = 2 rows x 4 MC samples of a 32 x 64 tile; the differences and squares are packed-fp32 instructions (two
+// elements each: v_pk_add_f32, v_pk_fma_f32 -- full rate where no MFMA runs beside them), accumulated per element parity and
+// added at the end of a 64-element chunk.  The next chunk's rows are fetched into registers while this one is multiplied.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// a - b on both halves in one instruction (hipcc scalarises a v2f32 subtraction, also when written as a + (-b) or fma(b, -1, a))
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
 __global__ __launch_bounds__(256) void guid_logp_kernel(const GuidanceArgs a_in) {
   const GuidanceArgs a = with_schedule(a_in);
   __shared__ __attribute__((aligned(16))) float sx[32 * GLD];
-  __shared__ __attribute__((aligned(16))) float sm[32 * GLD];
+  __shared__ __attribute__((aligned(16))) float sm[64 * GLD];
   const int tid = threadIdx.x;
   const int tb = tid >> 4, ti = tid & 15;
-  const int bb = blockIdx.x * 32, ib = blockIdx.y * 32;
+  const int bb = blockIdx.x * 32, ib = blockIdx.y * 64;
   const int z = blockIdx.z;
   const int part = z >= a.nsx ? 1 : 0;
   const float* X = part ? a.y : a.x;
@@ -47,58 +58,82 @@ __global__ __launch_bounds__(256) void guid_logp_kernel(const GuidanceArgs a_in)
   const int D = part ? a.dy : a.dx;
   const int dbeg = (part ? z - a.nsx : z) * a.slice_len;
   const int dend = dbeg + a.slice_len < D ? dbeg + a.slice_len : D;
+  // staging items: item it < 512 is (row it / 16, float4 it % 16) of x, the 1024 behind them of the MC set; six per thread
+  const float* src[6];
+  bool ok[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int it = tid + 256 * j;
+    const bool isx = it < 512;
+    const int row = isx ? it >> 4 : (it - 512) >> 4, q = it & 15;
+    const int grow = isx ? bb + row : ib + row;
+    ok[j] = isx ? grow < a.B : grow < a.N;
+    src[j] = (isx ? X : M) + (size_t)(ok[j] ? grow : 0) * D + q * 4;
+  }
+  f32x4 rv[6];
+  auto fetch = [&](int d0) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int d = d0 + (tid & 15) * 4;
+      const bool in = ok[j] && d < dend;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src[j] + (in ? d0 : dbeg));  // (clamped: always a valid address)
+      rv[j] = in ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
   // chunk partials in fp32 (64 terms), running total in fp64: the sum is then exact
   // to fp32 rounding, which matters because l is later scaled by 1/sigma_t^2 (up to ~8e3)
-  double S[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+  double S[2][4];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) S[p][q] = 0.0;
+  fetch(dbeg);
   for (int d0 = dbeg; d0 < dend; d0 += GD) {
     __syncthreads();
-    // 32 rows x 16 float4 for each operand: 512 items each, 2 per thread
-    for (int it = tid; it < 512; it += 256) {
-      const int row = it >> 4, q = it & 15;
-      const int d = d0 + q * 4;
-      f32x4 vx = {0.f, 0.f, 0.f, 0.f}, vm = {0.f, 0.f, 0.f, 0.f};
-      if (d < dend) {
-        if (bb + row < a.B) vx = *reinterpret_cast<const f32x4*>(X + (size_t)(bb + row) * D + d);
-        if (ib + row < a.N) {
-          vm = *reinterpret_cast<const f32x4*>(M + (size_t)(ib + row) * D + d);
-          vm.x = __fmul_rn(a.tf, vm.x);  // mu = t * x_1 (rounded, as the reference)
-          vm.y = __fmul_rn(a.tf, vm.y);
-          vm.z = __fmul_rn(a.tf, vm.z);
-          vm.w = __fmul_rn(a.tf, vm.w);
-        }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int it = tid + 256 * j;
+      f32x4 v = rv[j];
+      if (it >= 512) {  // mu = t * x_1 (rounded, as the reference)
+        v.x = __fmul_rn(a.tf, v.x), v.y = __fmul_rn(a.tf, v.y), v.z = __fmul_rn(a.tf, v.z), v.w = __fmul_rn(a.tf, v.w);
+        *reinterpret_cast<f32x4*>(sm + ((it - 512) >> 4) * GLD + (it & 15) * 4) = v;
+      } else {
+        *reinterpret_cast<f32x4*>(sx + (it >> 4) * GLD + (it & 15) * 4) = v;
       }
-      *reinterpret_cast<f32x4*>(sx + row * GLD + q * 4) = vx;
-      *reinterpret_cast<f32x4*>(sm + row * GLD + q * 4) = vm;
     }
     __syncthreads();
-    float c[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    if (d0 + GD < dend) fetch(d0 + GD);
+    f32x2 c[2][4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) c[p][q] = f32x2{0.f, 0.f};
 #pragma unroll
     for (int d = 0; d < GD; d += 4) {
-      f32x4 xv[2], mv[2];
-      xv[0] = *reinterpret_cast<const f32x4*>(sx + tb * GLD + d);
-      xv[1] = *reinterpret_cast<const f32x4*>(sx + (tb + 16) * GLD + d);
-      mv[0] = *reinterpret_cast<const f32x4*>(sm + ti * GLD + d);
-      mv[1] = *reinterpret_cast<const f32x4*>(sm + (ti + 16) * GLD + d);
+      f32x4 xv[2], mv[4];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) xv[p] = *reinterpret_cast<const f32x4*>(sx + (tb + 16 * p) * GLD + d);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mv[q] = *reinterpret_cast<const f32x4*>(sm + (ti + 16 * q) * GLD + d);
 #pragma unroll
       for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          float df;
-          df = xv[p].x - mv[q].x, c[p][q] += df * df;
-          df = xv[p].y - mv[q].y, c[p][q] += df * df;
-          df = xv[p].z - mv[q].z, c[p][q] += df * df;
-          df = xv[p].w - mv[q].w, c[p][q] += df * df;
+        for (int q = 0; q < 4; ++q) {
+          const f32x2 d0v = pk_sub(f32x2{xv[p].x, xv[p].y}, f32x2{mv[q].x, mv[q].y});
+          const f32x2 d1v = pk_sub(f32x2{xv[p].z, xv[p].w}, f32x2{mv[q].z, mv[q].w});
+          c[p][q] = __builtin_elementwise_fma(d0v, d0v, c[p][q]);
+          c[p][q] = __builtin_elementwise_fma(d1v, d1v, c[p][q]);
         }
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
-      for (int q = 0; q < 2; ++q) S[p][q] += (double)c[p][q];
+      for (int q = 0; q < 4; ++q) S[p][q] += (double)(c[p][q].x + c[p][q].y);
   }
 #pragma unroll
   for (int p = 0; p < 2; ++p)
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < 4; ++q) {
       const int b = bb + tb + 16 * p, i = ib + ti + 16 * q;
       if (b < a.B && i < a.N) a.dist[((size_t)z * a.B + b) * a.N + i] = S[p][q];
     }
@@ -161,77 +196,146 @@ __global__ __launch_bounds__(256) void guid_weights_kernel(const GuidanceArgs a_
     ws += w;
   }
   ws = __fadd_rn(wave_sum_g(ws), 1e-10f);
+  float rsum = 0.f;
   for (int i = lane; i < N; i += 64) {
     const float w = swr[i] / ws;
     a.wbuf[(size_t)b * N + i] = w;
     if (a.weights_out) a.weights_out[(size_t)b * N + i] = w;
+    rsum += w;
   }
+  rsum = wave_sum_g(rsum);  // the row's weight sum as guid_apply_mfma_kernel needs it (1 up to rounding and the epsilon)
+  if (lane == 0) a.wsum[b] = rsum;
 }
 
-// grid (ceil(B/16), ceil(D/256)); one launch per modality (part).  Wave w owns rows b0 + 4w .. + 3 (their weights sit
-// in a wave-private piece of LDS: no workgroup barrier), lane l the four components d0 + 4l .. + 3.  The four waves
-// of a workgroup stream the same 256-wide column block of the MC set, so it leaves L2 once per 16 rows, and the grid
-// has 512 workgroups at the benchmark shape (the first version: 4 rows x 1024 columns per workgroup, 128
-// workgroups, weights recomputed by every one of them).  Arithmetic and summation order are unchanged.
-template <int RW>  // rows per wave: 4 (16 rows per workgroup; N <= 1024), or 1 for larger MC sets (LDS: [4 RW][N] floats)
-__global__ __launch_bounds__(256) void guid_apply_kernel(const GuidanceArgs a_in, int part) {
+// The guided velocity g_b = sum_i w_bi (m_i - x_b) / c (sample_mnist_svhn.py:157-160) as the fp32 GEMM it is:
+//   g_b = (sum_i w_bi m_i  -  x_b sum_i w_bi) / c,   [B, N] x [N, D] on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32
+// accumulation: the arithmetic of an fmaf chain), then the blend (1 - gamma) v + gamma g and the optional Euler update in
+// the epilogue.  The first versions formed every (m_i - x_b) / c w_bi on the vector ALU in the reference's operation
+// order: 16 VALU instructions per (row, sample, float4), 110 us at B = 512, N = 256, D = 3072 + 1024 against 7 us of
+// matrix work.  Both forms carry the same error: terms of size |m - x| / c summed to a result that may be far smaller.
+//
+// grid (ceil(B / 32), ceil(dx / 128) + ceil(dy / 128)): both modalities in one launch; workgroup = a 32-row x 128-column output tile, its four
+// waves each take a quarter of the MC samples (the two lane halves of a wave: the two halves of that quarter, one
+// sample each per MFMA) and add their partial tiles through LDS in wave order.  Lane l supplies W[b0 + l % 32][k] as
+// the A element and M[k][d0 + 4 (l % 32) + j] as the B element of column tile j: one float4 of the MC set feeds four
+// MFMAs and the lane ends up with four consecutive columns of a row (float4 loads and stores in the epilogue).  A
+// row's result depends on its own weights and the MC set only, in an order fixed by N: independent of the batch it is in.
+template <bool W4>  // N % 32 == 0: a lane's run of samples starts at a multiple of four and its weights arrive as float4
+__global__ __launch_bounds__(256, 2) void guid_apply_mfma_kernel(const GuidanceArgs a_in) {
   const GuidanceArgs a = with_schedule(a_in);
-  extern __shared__ __attribute__((aligned(16))) float sw[];  // [4 RW][N]
+  const int nbx = (a.dx + 127) >> 7;  // column blocks of modality x; those of y behind them
+  const int part = (int)blockIdx.y >= nbx ? 1 : 0;
+  extern __shared__ __attribute__((aligned(16))) float sred[];  // [4 waves][64 accumulators][64 lanes]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int N = a.N;
-  const int b0 = blockIdx.x * (4 * RW) + wave * RW;
-  float* swv = sw + (size_t)wave * RW * N;
-#pragma unroll
-  for (int r = 0; r < RW; ++r)
-    for (int i = lane; i < N; i += 64) swv[r * N + i] = (b0 + r < a.B) ? a.wbuf[(size_t)(b0 + r) * N + i] : 0.f;
-  // (wave-private LDS: the lanes of this wave wrote what they now read; LDS operations of a wave execute in order)
-
+  const int l31 = lane & 31, hf = lane >> 5;
+  const int N = a.N, B = a.B;
   const float* X = part ? a.y : a.x;
   const float* M = part ? a.mc_y1 : a.mc_x1;
   float* V = part ? a.vy : a.vx;
   float* XS = part ? a.y_state : a.x_state;
   const int D = part ? a.dy : a.dx;
-  const int d = blockIdx.y * 256 + lane * 4;
-  if (d >= D) return;
-  f32x4 xv[RW], g[RW];
+  const int b0 = blockIdx.x * 32;
+  const int d = ((int)blockIdx.y - (part ? nbx : 0)) * 128 + 4 * l31;
+  const bool dok = d < D;
+  const int KH = (N + 7) >> 3;              // samples per (wave, lane half)
+  const int k0 = (wave * 2 + hf) * KH;
+  const bool rowok = b0 + l31 < B;
+  const float* wrow = a.wbuf + (size_t)(rowok ? b0 + l31 : 0) * N;
+  const float* mcol = M + (dok ? d : 0);
+  constexpr int U = 16;  // samples per group: two groups of registers, one being multiplied (64 MFMAs, 1.7 us) while the other loads
+  struct Grp {
+    float w[U];
+    f32x4 m[U];
+  };
+  auto load = [&](Grp& g, int s0) {  // (branch-free: clamped addresses, selects)
+    if constexpr (W4) {
 #pragma unroll
-  for (int r = 0; r < RW; ++r) {
-    g[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-    xv[r] = (b0 + r < a.B) ? *reinterpret_cast<const f32x4*>(X + (size_t)(b0 + r) * D + d) : g[r];
-  }
-  // (m - x) / (1 - t + eps) of the reference (sample_mnist_svhn.py:159) as a multiplication by the correctly rounded
-  // reciprocal: one more rounding (<= 1 ulp per term) for a loop that was 70 % division instructions
-  const float rcden = 1.0f / a.cden;
-  for (int i = 0; i < N; ++i) {
-    float w[RW];
-    bool any = false;
-#pragma unroll
-    for (int r = 0; r < RW; ++r) w[r] = swv[r * N + i], any = any || (w[r] != 0.f);
-    // exact skip: a zero weight contributes +0 to every sum
-    if (!any) continue;
-    const f32x4 m = *reinterpret_cast<const f32x4*>(M + (size_t)i * D + d);
-#pragma unroll
-    for (int r = 0; r < RW; ++r) {
-      if (w[r] != 0.f) {
-        g[r].x = __fadd_rn(g[r].x, __fmul_rn(w[r], __fmul_rn(m.x - xv[r].x, rcden)));
-        g[r].y = __fadd_rn(g[r].y, __fmul_rn(w[r], __fmul_rn(m.y - xv[r].y, rcden)));
-        g[r].z = __fadd_rn(g[r].z, __fmul_rn(w[r], __fmul_rn(m.z - xv[r].z, rcden)));
-        g[r].w = __fadd_rn(g[r].w, __fmul_rn(w[r], __fmul_rn(m.w - xv[r].w, rcden)));
+      for (int u = 0; u < U; u += 4) {
+        const int s = s0 + u;
+        const bool ok = s < KH && rowok;  // (whole quads: KH % 4 == 0)
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + (s < KH ? k0 + s : 0));
+        g.w[u] = ok ? wv.x : 0.f, g.w[u + 1] = ok ? wv.y : 0.f, g.w[u + 2] = ok ? wv.z : 0.f, g.w[u + 3] = ok ? wv.w : 0.f;
       }
     }
-  }
 #pragma unroll
-  for (int r = 0; r < RW; ++r) {
-    if (b0 + r >= a.B) continue;
-    const size_t o = (size_t)(b0 + r) * D + d;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(V + o);
-    f32x4 nv;
-    nv.x = __fadd_rn(__fmul_rn(a.g1, v.x), __fmul_rn(a.g2, g[r].x));
-    nv.y = __fadd_rn(__fmul_rn(a.g1, v.y), __fmul_rn(a.g2, g[r].y));
-    nv.z = __fadd_rn(__fmul_rn(a.g1, v.z), __fmul_rn(a.g2, g[r].z));
-    nv.w = __fadd_rn(__fmul_rn(a.g1, v.w), __fmul_rn(a.g2, g[r].w));
+    for (int u = 0; u < U; ++u) {
+      const int s = s0 + u, k = k0 + s;
+      const bool kok = s < KH && k < N;
+      const int kc = kok ? k : 0;
+      if constexpr (!W4) {
+        const float wv = wrow[kc];
+        g.w[u] = (kok && rowok) ? wv : 0.f;  // (a sample past the end enters as 0 x finite)
+      }
+      g.m[u] = *reinterpret_cast<const f32x4*>(mcol + (size_t)kc * D);
+    }
+  };
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  auto mult = [&](const Grp& g) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g.w[u], g.m[u].x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g.w[u], g.m[u].y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(g.w[u], g.m[u].z, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(g.w[u], g.m[u].w, acc[3], 0, 0, 0);
+    }
+  };
+  Grp g0, g1;  // (no register copies between iterations: a copy would wait for the loads it copies)
+  load(g0, 0);
+  for (int s0 = 0; s0 < KH; s0 += 2 * U) {
+    load(g1, s0 + U);  // (past the end: clamped addresses, zero weights)
+    mult(g0);
+    if (s0 + 2 * U < KH) load(g0, s0 + 2 * U);
+    if (s0 + U < KH) mult(g1);
+  }
+  // the epilogue's rows of x and v (this wave finishes rows b0 + 8 wave + 4 hf + 0 .. 3), fetched under the exchange of the partial tiles
+  f32x4 ex[4], ev[4];
+  float esw[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int b = b0 + 8 * wave + 4 * hf + rr;
+    const size_t o = (size_t)(b < B ? b : 0) * D + (dok ? d : 0);
+    ex[rr] = *reinterpret_cast<const f32x4*>(X + o);
+    ev[rr] = *reinterpret_cast<const f32x4*>(V + o);
+    esw[rr] = a.wsum[b < B ? b : 0];
+  }
+  // partial tiles -> LDS; wave w then owns accumulator rows r = 4w .. 4w + 3: output rows b0 + 8w + 4 (lane / 32) + (r & 3)
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sred[((wave * 64) + j * 16 + r) * 64 + lane] = acc[j][r];
+  __syncthreads();
+  const float rcden = 1.0f / a.cden;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int r = 4 * wave + rr;
+    const int b = b0 + 8 * wave + 4 * hf + rr;
+    float c[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float t = sred[(j * 16 + r) * 64 + lane];
+#pragma unroll
+      for (int p = 1; p < 4; ++p) t = __fadd_rn(t, sred[((p * 64) + j * 16 + r) * 64 + lane]);
+      c[j] = t;
+    }
+    if (b >= B || !dok) continue;
+    const size_t o = (size_t)b * D + d;
+    const f32x4 xv = ex[rr], v = ev[rr];
+    const float sw = esw[rr];
+    f32x4 g, nv;
+    g.x = __fmul_rn(__fsub_rn(c[0], __fmul_rn(xv.x, sw)), rcden);
+    g.y = __fmul_rn(__fsub_rn(c[1], __fmul_rn(xv.y, sw)), rcden);
+    g.z = __fmul_rn(__fsub_rn(c[2], __fmul_rn(xv.z, sw)), rcden);
+    g.w = __fmul_rn(__fsub_rn(c[3], __fmul_rn(xv.w, sw)), rcden);
+    nv.x = __fadd_rn(__fmul_rn(a.g1, v.x), __fmul_rn(a.g2, g.x));
+    nv.y = __fadd_rn(__fmul_rn(a.g1, v.y), __fmul_rn(a.g2, g.y));
+    nv.z = __fadd_rn(__fmul_rn(a.g1, v.z), __fmul_rn(a.g2, g.z));
+    nv.w = __fadd_rn(__fmul_rn(a.g1, v.w), __fmul_rn(a.g2, g.w));
     if (XS) {
-      f32x4 xs = xv[r];
+      f32x4 xs = xv;
       xs.x = __fadd_rn(xs.x, __fmul_rn(nv.x, a.dt));
       xs.y = __fadd_rn(xs.y, __fmul_rn(nv.y, a.dt));
       xs.z = __fadd_rn(xs.z, __fmul_rn(nv.z, a.dt));
@@ -244,21 +348,21 @@ __global__ __launch_bounds__(256) void guid_apply_kernel(const GuidanceArgs a_in
 }
 
 void launch_guid_logp(const GuidanceArgs& a, hipStream_t s) {
-  dim3 g1((a.B + 31) / 32, (a.N + 31) / 32, a.nsx + a.nsy);
+  dim3 g1((a.B + 31) / 32, (a.N + 63) / 64, a.nsx + a.nsy);
   hipLaunchKernelGGL(guid_logp_kernel, g1, dim3(256), 0, s, a);
+}
+
+int guid_apply_init() {  // (64 KB of dynamic LDS)
+  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&guid_apply_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) |
+         (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&guid_apply_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 }
 
 void launch_guid_apply(const GuidanceArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(guid_weights_kernel, dim3((a.B + 3) / 4), dim3(256), (size_t)4 * a.N * sizeof(float), s, a);
-  if ((size_t)16 * a.N * sizeof(float) <= 64 * 1024) {
-    const size_t lds = (size_t)16 * a.N * sizeof(float);
-    hipLaunchKernelGGL(guid_apply_kernel<4>, dim3((a.B + 15) / 16, (a.dx + 255) / 256), dim3(256), lds, s, a, 0);
-    hipLaunchKernelGGL(guid_apply_kernel<4>, dim3((a.B + 15) / 16, (a.dy + 255) / 256), dim3(256), lds, s, a, 1);
-  } else {  // (N <= 4096: rgfm_guidance_apply / the samplers check)
-    const size_t lds = (size_t)4 * a.N * sizeof(float);
-    hipLaunchKernelGGL(guid_apply_kernel<1>, dim3((a.B + 3) / 4, (a.dx + 255) / 256), dim3(256), lds, s, a, 0);
-    hipLaunchKernelGGL(guid_apply_kernel<1>, dim3((a.B + 3) / 4, (a.dy + 255) / 256), dim3(256), lds, s, a, 1);
-  }
+  const size_t lds = (size_t)4 * 64 * 64 * sizeof(float);
+  const dim3 grid((a.B + 31) / 32, (a.dx + 127) / 128 + (a.dy + 127) / 128);
+  if (a.N % 32 == 0) hipLaunchKernelGGL(guid_apply_mfma_kernel<true>, grid, dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(guid_apply_mfma_kernel<false>, grid, dim3(256), lds, s, a);
 }
 
 // x <- x + v * dt (mul, then add: two roundings like the reference's x_t + v * dt)

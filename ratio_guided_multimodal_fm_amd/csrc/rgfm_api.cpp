@@ -304,7 +304,8 @@ int ensure_init() {
   if (dev < 0 || dev >= MAX_DEVICES) return fail(RGFM_EINVAL, "device ordinal %d out of range (max %d)", dev, MAX_DEVICES - 1);
   DevState& d = g_dev[dev];
   if (!d.init) {
-    if (conv_mfma_init() != 0 || conv_bx3_init() != 0 || conv_hx2_init() != 0 || conv_hx2p_init() != 0 || conv_hx2q_init() != 0)
+    if (conv_mfma_init() != 0 || conv_bx3_init() != 0 || conv_hx2_init() != 0 || conv_hx2p_init() != 0 || conv_hx2q_init() != 0 ||
+        guid_apply_init() != 0)
       return fail(RGFM_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, dev) == hipSuccess) d.num_cus = p.multiProcessorCount;
@@ -1027,8 +1028,11 @@ extern "C" int rgfm_sample_single(rgfm_unet* h, float* x_inout, int batch, int n
 static size_t guid_dist_bytes(int batch, int n_mc) {  // sliced fp64 distances, RGFM_GUID_SLICES slices at most
   return (((size_t)RGFM_GUID_SLICES * batch * (n_mc > 0 ? n_mc : 1) * sizeof(double)) + 255) & ~(size_t)255;
 }
-static size_t guid_scratch_bytes(int batch, int n_mc) {  // + the step's importance weights [B][N]
-  return guid_dist_bytes(batch, n_mc) + ((((size_t)batch * (n_mc > 0 ? n_mc : 1) * sizeof(float)) + 255) & ~(size_t)255);
+static size_t guid_wbuf_bytes(int batch, int n_mc) {  // the step's importance weights [B][N]
+  return (((size_t)batch * (n_mc > 0 ? n_mc : 1) * sizeof(float)) + 255) & ~(size_t)255;
+}
+static size_t guid_scratch_bytes(int batch, int n_mc) {  // + the weights and their row sums [B]
+  return guid_dist_bytes(batch, n_mc) + guid_wbuf_bytes(batch, n_mc) + (((size_t)batch * sizeof(float) + 255) & ~(size_t)255);
 }
 
 extern "C" int rgfm_guidance_workspace_bytes(int batch, int n_mc, size_t* bytes) {
@@ -1062,7 +1066,8 @@ int guidance_launch(const float* x, const float* y, float* vx, float* vy, const 
   a.g1 = (float)(1.0 - gamma), a.g2 = (float)gamma;
   a.dist = reinterpret_cast<double*>(logp), a.weights_out = weights_out, a.x_state = xs, a.y_state = ys, a.dt = dt;
   a.wbuf = reinterpret_cast<float*>(reinterpret_cast<char*>(logp) + guid_dist_bytes(B, N));
-  a.slice_len = 1024;  // 1024-element slices unless that needs more than RGFM_GUID_SLICES of them
+  a.wsum = reinterpret_cast<float*>(reinterpret_cast<char*>(a.wbuf) + guid_wbuf_bytes(B, N));
+  a.slice_len = 512;  // 512-element slices (8 x 16 x 4 = 512 workgroups at the benchmark shape) unless that needs more than RGFM_GUID_SLICES of them
   while ((dx + a.slice_len - 1) / a.slice_len + (dy + a.slice_len - 1) / a.slice_len > RGFM_GUID_SLICES) a.slice_len *= 2;
   a.nsx = (dx + a.slice_len - 1) / a.slice_len, a.nsy = (dy + a.slice_len - 1) / a.slice_len;
   // algorithmic bytes.  logp: rows of x, y and the MC set in, the sliced fp64 distances out.  apply: the

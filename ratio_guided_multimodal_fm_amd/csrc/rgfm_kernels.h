@@ -306,6 +306,7 @@ struct GuidanceArgs {
   const int* step_ptr;
   float* weights_out;  // optional [B][N]
   float* wbuf;         // [B][N] importance weights of the step (scratch: behind the distance slices)
+  float* wsum;         // [B] their row sums (scratch: behind wbuf)
   float* x_state;      // optional fused Euler: x_state += dt * blended
   float* y_state;
   float dt;
@@ -313,6 +314,7 @@ struct GuidanceArgs {
 constexpr int RGFM_GUID_SLICES = 8;
 void launch_guid_logp(const GuidanceArgs& a, hipStream_t s);   // distances -> GuidanceArgs::dist
 void launch_guid_apply(const GuidanceArgs& a, hipStream_t s);  // weights, guided velocity, blend (+ Euler)
+int guid_apply_init();                                         // (once per process: the GEMM kernel's LDS size)
 void launch_euler(float* x, const float* v, size_t n, float dt, hipStream_t s);
 void launch_step_inc(int* step, hipStream_t s);  // *step += 1
 void launch_guid_schedule(float* sched, int step_begin, int ns, int num_steps, hipStream_t s);  // [ns][4] = {tf, s2, cden, 0}
