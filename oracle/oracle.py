@@ -142,27 +142,27 @@ def ratio_eval(kind, params, x, y, what="log_ratio", loss="disc", feature_dim=25
     return (out, feat) if want_feat else out
 
 
-def ratio_grad(params, x, y, loss="disc", feature_dim=256, hidden_dim=512):
-    """(d log_ratio / dx, d log_ratio / dy, log_ratio) of RatioEstimatorMNISTSVHN in eval mode."""
+def ratio_grad(params, x, y, loss="disc", feature_dim=256, hidden_dim=512, kind="mnist_svhn"):
+    """(d log_ratio / dx, d log_ratio / dy, log_ratio) of RatioEstimatorMNISTSVHN / RatioEstimator ("mnist28") in eval mode."""
     L = lib()
     params, pp = _f(params)
     x, xp = _f(x)
     y, yp = _f(y)
     n = x.shape[0]
     gx, gy, lr = np.empty_like(x), np.empty_like(y), np.empty(n, np.float32)
-    L.ro_ratio_grad(feature_dim, hidden_dim, _LOSS[loss], pp, xp, yp, gx.ctypes.data_as(F32P),
+    L.ro_ratio_grad(_KIND[kind], feature_dim, hidden_dim, _LOSS[loss], pp, xp, yp, gx.ctypes.data_as(F32P),
                     gy.ctypes.data_as(F32P), lr.ctypes.data_as(F32P), n)
     return gx, gy, lr
 
 
 def sample_pair_grad(desc_x, params_x, desc_y, params_y, ratio_params, x0, y0, num_steps, gamma, loss="disc",
-                     step_begin=0, step_end=None, feature_dim=256, hidden_dim=512):
+                     step_begin=0, step_end=None, feature_dim=256, hidden_dim=512, kind="mnist_svhn"):
     px, pxp = _f(params_x)
     py, pyp = _f(params_y)
     pr, prp = _f(ratio_params)
     x = np.array(x0, dtype=np.float32, order="C")
     y = np.array(y0, dtype=np.float32, order="C")
-    lib().ro_sample_pair_grad(ctypes.byref(desc_x), pxp, ctypes.byref(desc_y), pyp, feature_dim, hidden_dim,
+    lib().ro_sample_pair_grad(ctypes.byref(desc_x), pxp, ctypes.byref(desc_y), pyp, _KIND[kind], feature_dim, hidden_dim,
                               _LOSS[loss], prp, x.ctypes.data_as(F32P), y.ctypes.data_as(F32P), x.shape[0],
                               num_steps, ctypes.c_double(gamma), step_begin,
                               num_steps if step_end is None else step_end)

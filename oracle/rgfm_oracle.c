@@ -681,8 +681,9 @@ static void conv3x3_bwd_data(const float* g, int Co, int S, const float* w, int 
 
 typedef struct {
   int ci, co, S, pooled;
-  const float *cw, *bw, *bb, *rm, *rv;
-  float* z; /* BatchNorm output (pre-SiLU) [co,S,S] */
+  const float *cw, *bw, *bb, *rm, *rv; /* (GroupNorm encoder: bw / bb are the norm's weight / bias, rm / rv unused) */
+  float* z; /* BatchNorm output (pre-SiLU) [co,S,S]; GroupNorm encoder: the conv output (the norm's input) */
+  float mean[8], rstd[8]; /* GroupNorm encoder: per-group statistics of z */
 } enc_layer;
 
 /* forward of one BatchNorm encoder with the pre-activations kept; returns the number of layers */
@@ -767,30 +768,147 @@ static void bn_encoder_bwd(enc_layer* L, int nconv, const float* fw, int F, cons
   }
 }
 
-/* loss: 0 disc, 1 rulsif.  gx [1,32,32], gy [3,32,32]; returns log_ratio */
-static float ratio_grad_one(int F, int Hd, const float* params, const float* x, const float* y, int loss, float* gx,
+/* ImageEncoder (src/models/ratio_estimator.py:34-93) with what the reverse pass needs kept: conv outputs and the
+ * per-group statistics of their GroupNorm */
+static void gn_encoder_fwd_keep(cursor* c, const float* img, int S, int F, enc_layer* L, const float** fw_out, float* feat) {
+  static const int chans[5] = {1, 32, 64, 128, 128};
+  float* h = fmalloc((size_t)S * S);
+  memcpy(h, img, (size_t)S * S * sizeof(float));
+  for (int i = 0; i < 4; ++i) {
+    const int ci = chans[i], co = chans[i + 1], HW = S * S, cpg = co / 8;
+    L[i].ci = ci, L[i].co = co, L[i].S = S, L[i].pooled = i < 3;
+    L[i].cw = take(c, (size_t)co * ci * 9);
+    const float* cb = take(c, co);
+    L[i].bw = take(c, co), L[i].bb = take(c, co), L[i].rm = L[i].rv = NULL;
+    float* z = fmalloc((size_t)co * HW);
+    conv3x3(h, ci, S, S, L[i].cw, cb, co, 1, z);
+    free(h);
+    L[i].z = z;
+    for (int g = 0; g < 8; ++g) { /* the statistics exactly as groupnorm() takes them */
+      const float* p = z + (size_t)g * cpg * HW;
+      const size_t n = (size_t)cpg * HW;
+      double sm = 0.0, m2 = 0.0;
+      for (size_t k = 0; k < n; ++k) sm += p[k];
+      const double mean = sm / (double)n;
+      for (size_t k = 0; k < n; ++k) m2 += (p[k] - mean) * (p[k] - mean);
+      L[i].mean[g] = (float)mean, L[i].rstd[g] = (float)(1.0 / sqrt(m2 / (double)n + 1e-5));
+    }
+    h = fmalloc((size_t)co * HW);
+    groupnorm(z, co, HW, 8, L[i].bw, L[i].bb, 1, h);
+    if (i < 3) h = maxpool2(h, co, &S);
+  }
+  const float* fw = take(c, (size_t)F * 128);
+  const float* fb = take(c, F);
+  *fw_out = fw;
+  avgpool_fc(h, 128, S * S, fw, fb, F, feat);
+  free(h);
+}
+
+/* reverse pass of the GroupNorm encoder: gfeat [F] -> gimg [1, 28, 28]; frees the kept conv outputs.
+ * y = silu(u), u = gamma xhat + beta, xhat = (z - mean_g) rstd_g over the group's cpg x S x S values:
+ *   d z = rstd_g (d xhat - mean_g(d xhat) - xhat mean_g(d xhat xhat)),  d xhat = d u gamma   (nn.GroupNorm backward) */
+static void gn_encoder_bwd(enc_layer* L, const float* fw, int F, const float* gfeat, float* gimg) {
+  const int Cl = L[3].co;
+  int S = L[3].S; /* no pool between conv4 and the average pool */
+  float* g = fmalloc((size_t)Cl * S * S);
+  for (int ch = 0; ch < Cl; ++ch) {
+    float a = 0.0f;
+    for (int f = 0; f < F; ++f) a += fw[(size_t)f * Cl + ch] * gfeat[f];
+    a /= (float)(S * S);
+    for (int p = 0; p < S * S; ++p) g[(size_t)ch * S * S + p] = a;
+  }
+  for (int i = 3; i >= 0; --i) {
+    const int co = L[i].co, ci = L[i].ci, Sz = L[i].S, HW = Sz * Sz, cpg = co / 8;
+    /* u = GroupNorm output (pre-SiLU), recomputed */
+    float* u = fmalloc((size_t)co * HW);
+    groupnorm(L[i].z, co, HW, 8, L[i].bw, L[i].bb, 0, u);
+    float* gu = fmalloc((size_t)co * HW);
+    if (L[i].pooled) { /* F.max_pool2d(., 2) (floor: the last row / column of an odd map gets no gradient), then SiLU' */
+      const int So = Sz / 2;
+      memset(gu, 0, (size_t)co * HW * sizeof(float));
+      for (int ch = 0; ch < co; ++ch)
+        for (int y = 0; y < So; ++y)
+          for (int x = 0; x < So; ++x) {
+            const float* up = u + ((size_t)ch * Sz + 2 * y) * Sz + 2 * x;
+            int best = 0;
+            float bv = silu(up[0]);
+            const int offs[4] = {0, 1, Sz, Sz + 1};
+            for (int k = 1; k < 4; ++k) {
+              const float v = silu(up[offs[k]]);
+              if (v > bv) bv = v, best = k;
+            }
+            const size_t o = ((size_t)ch * Sz + 2 * y) * Sz + 2 * x + offs[best];
+            gu[o] = g[((size_t)ch * So + y) * So + x] * dsilu(u[o]);
+          }
+    } else {
+      for (size_t p = 0; p < (size_t)co * HW; ++p) gu[p] = g[p] * dsilu(u[p]);
+    }
+    free(g);
+    free(u);
+    float* gz = fmalloc((size_t)co * HW);
+    for (int gr = 0; gr < 8; ++gr) {
+      const size_t n = (size_t)cpg * HW;
+      double s1 = 0.0, s2 = 0.0;
+      for (int c = 0; c < cpg; ++c) {
+        const int ch = gr * cpg + c;
+        for (int p = 0; p < HW; ++p) {
+          const float xh = (L[i].z[(size_t)ch * HW + p] - L[i].mean[gr]) * L[i].rstd[gr];
+          const float gx = gu[(size_t)ch * HW + p] * L[i].bw[ch];
+          s1 += gx, s2 += (double)gx * xh;
+        }
+      }
+      const float m1 = (float)(s1 / (double)n), m2 = (float)(s2 / (double)n);
+      for (int c = 0; c < cpg; ++c) {
+        const int ch = gr * cpg + c;
+        for (int p = 0; p < HW; ++p) {
+          const float xh = (L[i].z[(size_t)ch * HW + p] - L[i].mean[gr]) * L[i].rstd[gr];
+          gz[(size_t)ch * HW + p] = L[i].rstd[gr] * (gu[(size_t)ch * HW + p] * L[i].bw[ch] - m1 - xh * m2);
+        }
+      }
+    }
+    free(gu);
+    float* gin = i == 0 ? gimg : fmalloc((size_t)ci * HW);
+    conv3x3_bwd_data(gz, co, Sz, L[i].cw, ci, gin);
+    free(gz);
+    free(L[i].z);
+    g = gin;
+  }
+}
+
+/* loss: 0 disc, 1 rulsif.  RO_RATIO_MNIST_SVHN: gx [1,32,32], gy [3,32,32]; RO_RATIO_MNIST28 (RatioEstimator,
+ * src/models/ratio_estimator.py:96-191): gx, gy [1,28,28].  Returns log_ratio */
+static float ratio_grad_one(int kind, int F, int Hd, const float* params, const float* x, const float* y, int loss, float* gx,
                             float* gy) {
   static const int cm[5] = {1, 32, 64, 128, 128}, pm[4] = {1, 1, 1, 0};
   static const int cs[9] = {3, 64, 64, 128, 128, 256, 256, 256, 256};
   static const int ps[8] = {0, 1, 0, 1, 0, 1, 0, 1};
+  const int ms = kind == RO_RATIO_MNIST_SVHN;
   cursor c = {params};
   enc_layer Lm[4], Ls[8];
   const float *fwm, *fws;
   float feat[1024];
-  bn_encoder_fwd_keep(&c, x, 32, cm, 4, pm, F, Lm, &fwm, feat);
-  bn_encoder_fwd_keep(&c, y, 32, cs, 8, ps, F, Ls, &fws, feat + F);
-  /* score_net forward, inputs and pre-LayerNorm values kept */
-  const int dims[4] = {2 * F, Hd, Hd, Hd / 2};
-  const float *W[3], *lw[3];
+  if (ms) {
+    bn_encoder_fwd_keep(&c, x, 32, cm, 4, pm, F, Lm, &fwm, feat);
+    bn_encoder_fwd_keep(&c, y, 32, cs, 8, ps, F, Ls, &fws, feat + F);
+  } else {
+    gn_encoder_fwd_keep(&c, x, 28, F, Lm, &fwm, feat);
+    gn_encoder_fwd_keep(&c, y, 28, F, Ls, &fws, feat + F);
+  }
+  /* score_net forward (ratio_flexible.py:332-345: 3 hidden layers; ratio_estimator.py:125-135: 2), inputs and
+   * pre-LayerNorm values kept */
+  int dims[4], nl;
+  if (ms) dims[0] = 2 * F, dims[1] = Hd, dims[2] = Hd, dims[3] = Hd / 2, nl = 3;
+  else dims[0] = 2 * F, dims[1] = Hd, dims[2] = Hd / 2, dims[3] = 0, nl = 2;
+  const float *W[3], *lw[3], *lbs[3];
   float *in[4], *u[3];
   float mean[3], rstd[3];
   in[0] = fmalloc(2 * F);
   memcpy(in[0], feat, 2 * F * sizeof(float));
-  for (int l = 0; l < 3; ++l) {
+  for (int l = 0; l < nl; ++l) {
     W[l] = take(&c, (size_t)dims[l + 1] * dims[l]);
     const float* b = take(&c, dims[l + 1]);
     lw[l] = take(&c, dims[l + 1]);
-    const float* lb = take(&c, dims[l + 1]);
+    lbs[l] = take(&c, dims[l + 1]);
     const int n = dims[l + 1];
     u[l] = fmalloc(n);
     linear(W[l], b, in[l], dims[l], n, u[l]);
@@ -801,14 +919,12 @@ static float ratio_grad_one(int F, int Hd, const float* params, const float* x, 
     for (int i = 0; i < n; ++i) m2 += (u[l][i] - mu) * (u[l][i] - mu);
     mean[l] = (float)mu, rstd[l] = (float)(1.0 / sqrt(m2 / n + 1e-5));
     in[l + 1] = fmalloc(n);
-    for (int i = 0; i < n; ++i) in[l + 1][i] = silu((u[l][i] - mean[l]) * rstd[l] * lw[l][i] + lb[i]);
-    /* keep v = LN output in u[l] slot? no: recomputed below from u, mean, rstd */
-    (void)lb;
+    for (int i = 0; i < n; ++i) in[l + 1][i] = silu((u[l][i] - mean[l]) * rstd[l] * lw[l][i] + lbs[l][i]);
   }
-  const float* hw = take(&c, dims[3]);
+  const float* hw = take(&c, dims[nl]);
   const float* hb = take(&c, 1);
   float s;
-  linear(hw, hb, in[3], dims[3], 1, &s);
+  linear(hw, hb, in[nl], dims[nl], 1, &s);
   float lr, ds;
   if (loss == 0) {
     lr = logsigmoidf(s) - logsigmoidf(-s);
@@ -819,26 +935,9 @@ static float ratio_grad_one(int F, int Hd, const float* params, const float* x, 
     ds = (s > 20.0f ? 1.0f : sigmoidf_(s)) / (w + 1e-8f);
   }
   /* reverse: head */
-  float* g = fmalloc(dims[3]);
-  for (int i = 0; i < dims[3]; ++i) g[i] = ds * hw[i];
-  /* the LayerNorm biases are needed again: re-walk the parameter block */
-  cursor c2 = {params};
-  ratio_walk(RO_RATIO_MNIST_SVHN, F, Hd, NULL, NULL, NULL, 0, 0, NULL, NULL); /* (layout check only) */
-  {
-    /* skip the encoders */
-    for (int i = 0; i < 4; ++i) take(&c2, (size_t)cm[i + 1] * cm[i] * 9 + 5 * cm[i + 1] + 1);
-    take(&c2, (size_t)F * 128 + F);
-    for (int i = 0; i < 8; ++i) take(&c2, (size_t)cs[i + 1] * cs[i] * 9 + 5 * cs[i + 1] + 1);
-    take(&c2, (size_t)F * 256 + F);
-  }
-  const float* lbs[3];
-  for (int l = 0; l < 3; ++l) {
-    take(&c2, (size_t)dims[l + 1] * dims[l]);
-    take(&c2, dims[l + 1]);
-    take(&c2, dims[l + 1]);
-    lbs[l] = take(&c2, dims[l + 1]);
-  }
-  for (int l = 2; l >= 0; --l) {
+  float* g = fmalloc(dims[nl]);
+  for (int i = 0; i < dims[nl]; ++i) g[i] = ds * hw[i];
+  for (int l = nl - 1; l >= 0; --l) {
     const int n = dims[l + 1];
     /* y = silu(v), v = gamma * uhat + beta, uhat = (u - mean) * rstd */
     float* guh = fmalloc(n);
@@ -866,20 +965,27 @@ static float ratio_grad_one(int F, int Hd, const float* params, const float* x, 
     }
     free(gu);
   }
-  bn_encoder_bwd(Lm, 4, fwm, F, g, gx);
-  bn_encoder_bwd(Ls, 8, fws, F, g + F, gy);
+  if (ms) {
+    bn_encoder_bwd(Lm, 4, fwm, F, g, gx);
+    bn_encoder_bwd(Ls, 8, fws, F, g + F, gy);
+  } else {
+    gn_encoder_bwd(Lm, fwm, F, g, gx);
+    gn_encoder_bwd(Ls, fws, F, g + F, gy);
+  }
   free(g);
-  for (int l = 0; l < 3; ++l) free(u[l]);
-  for (int l = 0; l < 4; ++l) free(in[l]);
+  for (int l = 0; l < nl; ++l) free(u[l]);
+  for (int l = 0; l <= nl; ++l) free(in[l]);
   return lr;
 }
 
-void ro_ratio_grad(int feature_dim, int hidden_dim, int loss, const float* params, const float* x, const float* y,
+void ro_ratio_grad(int kind, int feature_dim, int hidden_dim, int loss, const float* params, const float* x, const float* y,
                    float* gx, float* gy, float* log_ratio, int n) {
+  const size_t nx = kind == RO_RATIO_MNIST_SVHN ? 1024 : 784;
+  const size_t ny = kind == RO_RATIO_MNIST_SVHN ? 3072 : 784;
 #pragma omp parallel for schedule(dynamic)
   for (int i = 0; i < n; ++i) {
-    const float lr = ratio_grad_one(feature_dim, hidden_dim, params, x + (size_t)i * 1024, y + (size_t)i * 3072, loss,
-                                    gx + (size_t)i * 1024, gy + (size_t)i * 3072);
+    const float lr = ratio_grad_one(kind, feature_dim, hidden_dim, params, x + (size_t)i * nx, y + (size_t)i * ny, loss,
+                                    gx + (size_t)i * nx, gy + (size_t)i * ny);
     if (log_ratio) log_ratio[i] = lr;
   }
 }
@@ -887,7 +993,7 @@ void ro_ratio_grad(int feature_dim, int hidden_dim, int loss, const float* param
 /* Gradient log-ratio guidance (reference README.md:159-164: v_guided = v_ind + gamma * grad log r(x_t, y_t)), explicit
  * Euler as the other samplers: x <- x + (v_x + gamma g_x) dt.  The reference ships no code for this mode: the
  * composition is this build's reading of the README line ("parity unpinned"); the gradient itself is pinned. */
-void ro_sample_pair_grad(const ro_unet_desc* ddx, const float* px, const ro_unet_desc* ddy, const float* py,
+void ro_sample_pair_grad(const ro_unet_desc* ddx, const float* px, const ro_unet_desc* ddy, const float* py, int kind,
                          int feature_dim, int hidden_dim, int loss, const float* pr, float* x, float* y, int B,
                          int num_steps, double gamma, int step_begin, int step_end) {
   const size_t dx = (size_t)ddx->in_channels * ddx->img_size * ddx->img_size;
@@ -902,7 +1008,7 @@ void ro_sample_pair_grad(const ro_unet_desc* ddx, const float* px, const ro_unet
     const float t = (float)((double)s * dtd);
     ro_unet_forward(ddx, px, x, &t, 1, vx, B, NULL);
     ro_unet_forward(ddy, py, y, &t, 1, vy, B, NULL);
-    ro_ratio_grad(feature_dim, hidden_dim, loss, pr, x, y, gx, gy, NULL, B);
+    ro_ratio_grad(kind, feature_dim, hidden_dim, loss, pr, x, y, gx, gy, NULL, B);
     for (size_t i = 0; i < B * dx; ++i) x[i] = x[i] + (vx[i] + gf * gx[i]) * dt;
     for (size_t i = 0; i < B * dy; ++i) y[i] = y[i] + (vy[i] + gf * gy[i]) * dt;
   }

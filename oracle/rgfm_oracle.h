@@ -46,11 +46,12 @@ size_t ro_ratio_param_floats(int kind, int feature_dim, int hidden_dim);
 void ro_ratio_eval(int kind, int feature_dim, int hidden_dim, int loss, const float* params,
                    const float* x, const float* y, float* out, int n, int what, float* feat);
 
-/* d log_ratio / d(x, y) of RatioEstimatorMNISTSVHN (eval mode): gx [n,1,32,32], gy [n,3,32,32]; log_ratio optional [n] */
-void ro_ratio_grad(int feature_dim, int hidden_dim, int loss, const float* params, const float* x, const float* y,
+/* d log_ratio / d(x, y) (eval mode) of RatioEstimatorMNISTSVHN (kind 0: gx [n,1,32,32], gy [n,3,32,32]) or
+ * RatioEstimator (kind 1: gx, gy [n,1,28,28]); log_ratio optional [n] */
+void ro_ratio_grad(int kind, int feature_dim, int hidden_dim, int loss, const float* params, const float* x, const float* y,
                    float* gx, float* gy, float* log_ratio, int n);
 /* paired Euler loop with gradient log-ratio guidance: x <- x + (v_x + gamma dlogr/dx) dt (README.md:159-164) */
-void ro_sample_pair_grad(const ro_unet_desc* dx, const float* px, const ro_unet_desc* dy, const float* py,
+void ro_sample_pair_grad(const ro_unet_desc* dx, const float* px, const ro_unet_desc* dy, const float* py, int kind,
                          int feature_dim, int hidden_dim, int loss, const float* pr, float* x, float* y, int B,
                          int num_steps, double gamma, int step_begin, int step_end);
 

@@ -427,6 +427,26 @@ def gen_ratio_grad():
     save("ratio_grad", **out)
 
 
+def gen_ratio_grad28():
+    """The same for the 28x28 RatioEstimator (GroupNorm encoders, ratio_estimator.py:34-191): torch.autograd on the
+    reference module in eval mode, both loss types, noise-like and image-like inputs."""
+    out = {}
+    g = torch.Generator().manual_seed(86)
+    x = torch.randn(3, 1, 28, 28, generator=g)
+    y = torch.randn(3, 1, 28, 28, generator=g)
+    out["x_fp"], out["y_fp"] = n(x.reshape(-1)[:8]), n(y.reshape(-1)[:8])
+    for loss in ("disc", "rulsif"):
+        ref = build(RefRatio28, ours.RatioEstimator, SEED_W["ratio28"])
+        ref.loss_type = loss
+        for tag, scale in (("n", 1.0), ("s", 0.3)):
+            xx = (x * scale).clone().requires_grad_(True)
+            yy = (y * scale).clone().requires_grad_(True)
+            lr = ref.log_ratio(xx, yy)
+            gx, gy = torch.autograd.grad(lr.sum(), (xx, yy))
+            out[f"{loss}_{tag}_lr"], out[f"{loss}_{tag}_gx"], out[f"{loss}_{tag}_gy"] = n(lr.detach()), n(gx), n(gy)
+    save("ratio_grad28", **out)
+
+
 def gen_coherence28():
     """MNISTClassifier (src/models/classifier.py) logits on the golden 28x28 pairs.  src/evaluate.py itself
     cannot be imported here (it needs torchvision), so the coherence value is its :84-91 restated on the
@@ -470,9 +490,9 @@ def gen_fm_original():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["embedding", "unet_layers", "ratio", "guidance", "samplers", "coherence", "fm_original", "coherence28", "fp64", "unet_generic", "sweep200", "ratio_grad"]
+    which = sys.argv[1:] or ["embedding", "unet_layers", "ratio", "guidance", "samplers", "coherence", "fm_original", "coherence28", "fp64", "unet_generic", "sweep200", "ratio_grad", "ratio_grad28"]
     for w in which:
         {"embedding": gen_embedding, "unet_layers": gen_unet_layers, "ratio": gen_ratio,
          "guidance": gen_guidance, "samplers": gen_samplers, "coherence": gen_coherence,
          "fm_original": gen_fm_original, "coherence28": gen_coherence28, "fp64": gen_fp64, "unet_generic": gen_unet_generic,
-         "sweep200": gen_sweep200, "ratio_grad": gen_ratio_grad}[w]()
+         "sweep200": gen_sweep200, "ratio_grad": gen_ratio_grad, "ratio_grad28": gen_ratio_grad28}[w]()
