@@ -148,8 +148,9 @@ int rgfm_ratio_eval(rgfm_ratio* h, const float* x, const float* y, float* out, i
                     void* ws, size_t ws_bytes, rgfm_stream_t stream);
 
 /* Gradient of the log-ratio, d log_ratio(x, y) / d(x, y): what torch.autograd.grad(model.log_ratio(x, y).sum(),
- * (x, y)) returns for the reference module in eval mode (ratio_flexible.py:347-385; hand-written reverse pass).
- * gx[n,1,32,32], gy[n,3,32,32]; log_ratio_out (optional) [n].  RGFM_RATIO_MNIST_SVHN only (RGFM_EINVAL otherwise). */
+ * (x, y)) returns for the reference module in eval mode (ratio_flexible.py:347-385, ratio_estimator.py:137-191;
+ * hand-written reverse pass).  RGFM_RATIO_MNIST_SVHN: gx[n,1,32,32], gy[n,3,32,32]; RGFM_RATIO_MNIST28: gx, gy
+ * [n,1,28,28]; log_ratio_out (optional) [n]. */
 int rgfm_ratio_grad_workspace_bytes(const rgfm_ratio* h, int n, size_t* bytes);
 int rgfm_ratio_grad_log_ratio(rgfm_ratio* h, const float* x, const float* y, float* gx, float* gy,
                               float* log_ratio_out, int n, void* ws, size_t ws_bytes, rgfm_stream_t stream);
@@ -191,7 +192,8 @@ int rgfm_sample_pair(rgfm_unet* hx, rgfm_unet* hy, float* x_inout, float* y_inou
  *     x <- x + (v_x(x, t) + gamma * d log r(x, y)/dx) dt,   y likewise
  * (reference README.md:159-164, "v_guided = v_ind + gamma * grad log r(x_t, y_t)").  The reference ships no code
  * for this mode, so the composition above is this library's reading of that line; the gradient itself is the
- * autograd gradient of the reference module (rgfm_ratio_grad_log_ratio).  MNIST32 + SVHN pair only. */
+ * autograd gradient of the reference module (rgfm_ratio_grad_log_ratio).  The pair must be the estimator's:
+ * 1x32x32 + 3x32x32 (RGFM_RATIO_MNIST_SVHN) or 1x28x28 + 1x28x28 (RGFM_RATIO_MNIST28). */
 int rgfm_sample_pair_grad_workspace_bytes(const rgfm_unet* hx, const rgfm_unet* hy, const rgfm_ratio* hr,
                                           int batch, size_t* bytes);
 int rgfm_sample_pair_grad(rgfm_unet* hx, rgfm_unet* hy, rgfm_ratio* hr, float* x_inout, float* y_inout,

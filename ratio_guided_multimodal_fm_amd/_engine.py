@@ -387,16 +387,15 @@ class RatioEngine(_EngineBase):
 
 
     def grad_log_ratio(self, x, y):
-        """(d log_ratio/dx, d log_ratio/dy, log_ratio): rgfm_ratio_grad_log_ratio (MNIST-SVHN estimator only)."""
+        """(d log_ratio/dx, d log_ratio/dy, log_ratio): rgfm_ratio_grad_log_ratio (either estimator)."""
         m = self._module()
         self._check_eval(m)
         _require_hip(x, y)
-        if self.kind != "mnist_svhn":
-            raise _lib.RgfmError("the log-ratio gradient is implemented for RatioEstimatorMNISTSVHN only")
         if x.shape[0] != y.shape[0]:
             raise _lib.RgfmError("x and y must have the same batch size")
-        if x.dim() != 4 or y.dim() != 4 or tuple(x.shape[1:]) != (1, 32, 32) or tuple(y.shape[1:]) != (3, 32, 32):
-            raise _lib.RgfmError("expected x of shape [B,1,32,32] and y of shape [B,3,32,32], got "
+        sx, sy = ((1, 32, 32), (3, 32, 32)) if self.kind == "mnist_svhn" else ((1, 28, 28), (1, 28, 28))
+        if x.dim() != 4 or y.dim() != 4 or tuple(x.shape[1:]) != sx or tuple(y.shape[1:]) != sy:
+            raise _lib.RgfmError(f"expected x of shape [B,{sx[0]},{sx[1]},{sx[2]}] and y of shape [B,{sy[0]},{sy[1]},{sy[2]}], got "
                                  f"{tuple(x.shape)} and {tuple(y.shape)}")
         n = x.shape[0]
         x, y = x.contiguous(), y.contiguous()
@@ -524,8 +523,6 @@ def sample_pair_grad(fm_x, fm_y, ratio_estimator, x, y, num_steps, gamma, step_b
         m._engine._check_eval(m)
     if not (isinstance(fm_x._engine, UNetEngine) and isinstance(fm_y._engine, UNetEngine)):
         raise _lib.RgfmError("gradient log-ratio guidance needs two U-Net velocity nets")
-    if ratio_estimator._engine.kind != "mnist_svhn":
-        raise _lib.RgfmError("gradient log-ratio guidance is implemented for RatioEstimatorMNISTSVHN only")
     _require_hip(x, y)
     if not (x.is_contiguous() and y.is_contiguous()):
         raise _lib.RgfmError("x and y must be contiguous (they are updated in place)")

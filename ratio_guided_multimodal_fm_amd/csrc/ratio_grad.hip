@@ -59,11 +59,26 @@ __device__ __forceinline__ float sigmoid_fast(float v) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));
 }
 
-// one thread per (sample, output-side pixel group, 4 channels)
+// one thread per (sample, output-side pixel group, 4 channels).  GN (the GroupNorm encoders of RatioEstimator,
+// ratio_estimator.py:75-88): z is the conv output, the activation's argument is u = a z + b with the sample's
+// scale/shift pairs ab [B][C][2] (gn_finalize), and the result is d/du -- the norm's own backward follows
+// (gn_bwd_kernel); otherwise z is the folded-BatchNorm output and `scale` its per-channel factor.
+template <bool GN>
 __global__ __launch_bounds__(256) void grad_act_kernel(const float* __restrict__ g, const float* __restrict__ z,
                                                        const float* __restrict__ scale, float* __restrict__ gz, int B, int S,
                                                        int C, int mode) {
   const int C4 = C / 4;
+  // u = ea z + eb per element (GN), scale factor of the result
+  auto norm_of = [&](int b, int c4, f32x4& ea, f32x4& eb, f32x4& sc) {
+    if (GN) {
+      const f32x4* p = reinterpret_cast<const f32x4*>(scale + ((size_t)b * C + c4 * 4) * 2);
+      const f32x4 e0 = p[0], e1 = p[1];
+      ea = f32x4{e0.x, e0.z, e1.x, e1.z}, eb = f32x4{e0.y, e0.w, e1.y, e1.w}, sc = f32x4{1.f, 1.f, 1.f, 1.f};
+    } else {
+      ea = f32x4{1.f, 1.f, 1.f, 1.f}, eb = f32x4{0.f, 0.f, 0.f, 0.f};
+      sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
+    }
+  };
   if (mode == 1 || mode == 3) {
     const int So = S / 2;
     const float inv_o = 1.0f / (float)(So * So);
@@ -78,13 +93,15 @@ __global__ __launch_bounds__(256) void grad_act_kernel(const float* __restrict__
       f32x4 gv;
       if (mode == 3) gv = *reinterpret_cast<const f32x4*>(g + (size_t)b * C + c4 * 4) * inv_o;
       else gv = *reinterpret_cast<const f32x4*>(g + ((size_t)(b * So + oy) * So + ox) * C + c4 * 4);
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
+      f32x4 ea, eb, sc;
+      norm_of(b, c4, ea, eb, sc);
       f32x4 zv[4];
       size_t off[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         off[k] = ((size_t)(b * S + 2 * oy + (k >> 1)) * S + 2 * ox + (k & 1)) * C + c4 * 4;
         zv[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(z + off[k]));
+        if (GN) zv[k] = zv[k] * ea + eb;
       }
       f32x4 o[4];
 #pragma unroll
@@ -114,8 +131,10 @@ __global__ __launch_bounds__(256) void grad_act_kernel(const float* __restrict__
       const int c4 = i % C4;
       const size_t px = i / C4;
       const size_t b = px / ((size_t)S * S);
-      const f32x4 zv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(z + px * C + c4 * 4));
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
+      f32x4 zv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(z + px * C + c4 * 4));
+      f32x4 ea, eb, sc;
+      norm_of((int)b, c4, ea, eb, sc);
+      if (GN) zv = zv * ea + eb;
       f32x4 gv;
       if (mode == 2) {
         gv = *reinterpret_cast<const f32x4*>(g + b * C + c4 * 4);
@@ -136,7 +155,66 @@ __global__ __launch_bounds__(256) void grad_act_kernel(const float* __restrict__
 void launch_grad_act(const float* g, const float* z, const float* scale, float* gz, int B, int S, int C, int mode, hipStream_t s) {
   const size_t total = (size_t)B * ((mode == 1 || mode == 3) ? (S / 2) * (S / 2) : S * S) * (C / 4);
   const unsigned blocks = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-  hipLaunchKernelGGL(grad_act_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, g, z, scale, gz, B, S, C, mode);
+  hipLaunchKernelGGL(grad_act_kernel<false>, dim3(blocks ? blocks : 1), dim3(256), 0, s, g, z, scale, gz, B, S, C, mode);
+}
+// GroupNorm encoders: ab = the samples' scale/shift pairs; an odd map's last row and column are outside every 2x2
+// window (F.max_pool2d floors) and get a zero gradient
+void launch_grad_act_gn(const float* g, const float* z, const float* ab, float* gu, int B, int S, int C, int mode, hipStream_t s) {
+  const bool pooled = mode == 1 || mode == 3;
+  if (pooled && (S & 1)) (void)hipMemsetAsync(gu, 0, (size_t)B * S * S * C * sizeof(float), s);
+  const size_t total = (size_t)B * (pooled ? (S / 2) * (S / 2) : S * S) * (C / 4);
+  const unsigned blocks = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  hipLaunchKernelGGL(grad_act_kernel<true>, dim3(blocks ? blocks : 1), dim3(256), 0, s, g, z, ab, gu, B, S, C, mode);
+}
+
+// nn.GroupNorm backward, in place on gu (d/du, u = gamma xhat + beta) -> d/dz, one workgroup per (sample, group):
+//   d xhat = d u gamma,  d z = rstd (d xhat - mean(d xhat) - xhat mean(d xhat xhat)),  xhat = (z - mean) rstd
+// with (mean, rstd) of the group from gn_finalize (GnFinalizeArgs::mr).  A group is cpg channels x S x S values
+// (3136 at most in the 28x28 encoders): two passes over data that stays in L2.
+__global__ __launch_bounds__(256) void gn_bwd_kernel(float* __restrict__ gu, const float* __restrict__ z,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mr, int HW, int C,
+                                                     int groups) {
+  __shared__ double red[2][256];
+  const int b = blockIdx.x / groups, gi = blockIdx.x - b * groups;
+  const int cpg = C / groups, q4 = cpg / 4;  // (cpg is a multiple of 4)
+  const float mean = mr[((size_t)b * groups + gi) * 2], rstd = mr[((size_t)b * groups + gi) * 2 + 1];
+  const int items = HW * q4;
+  double s1 = 0.0, s2 = 0.0;
+  for (int it = threadIdx.x; it < items; it += 256) {
+    const int p = it / q4, q = it - p * q4;
+    const size_t o = ((size_t)b * HW + p) * C + gi * cpg + q * 4;
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(gu + o), zv = *reinterpret_cast<const f32x4*>(z + o);
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + gi * cpg + q * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gx = gv[e] * gm[e], xh = (zv[e] - mean) * rstd;
+      s1 += (double)gx, s2 += (double)gx * (double)xh;
+    }
+  }
+  red[0][threadIdx.x] = s1, red[1][threadIdx.x] = s2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[0][threadIdx.x] += red[0][threadIdx.x + o], red[1][threadIdx.x] += red[1][threadIdx.x + o];
+    __syncthreads();
+  }
+  const double n = (double)HW * (double)cpg;
+  const float m1 = (float)(red[0][0] / n), m2 = (float)(red[1][0] / n);
+  for (int it = threadIdx.x; it < items; it += 256) {
+    const int p = it / q4, q = it - p * q4;
+    const size_t o = ((size_t)b * HW + p) * C + gi * cpg + q * 4;
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(gu + o), zv = *reinterpret_cast<const f32x4*>(z + o);
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + gi * cpg + q * 4);
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (zv[e] - mean) * rstd;
+      r[e] = rstd * (gv[e] * gm[e] - m1 - xh * m2);
+    }
+    *reinterpret_cast<f32x4*>(gu + o) = r;
+  }
+}
+void launch_gn_bwd(float* gu, const float* z, const float* gamma, const float* mr, int B, int HW, int C, int groups, hipStream_t s) {
+  hipLaunchKernelGGL(gn_bwd_kernel, dim3(B * groups), dim3(256), 0, s, gu, z, gamma, mr, HW, C, groups);
 }
 
 // gimg[b][c][y][x] = sum_{co, ky, kx} w[co][c][ky][kx] gz[b][y - ky + 1][x - kx + 1][co].  One thread per output

@@ -1541,7 +1541,7 @@ extern "C" int rgfm_ratio_create(const rgfm_ratio_desc* desc, const float* param
         launch_bn_fold(h->params + cv.nw, h->params + cv.nb, h->params + cv.rm, h->params + cv.rv,
                        h->bn + cv.bn_scale, h->bn + cv.bn_shift, cv.w.cout, s);
     }
-  if (desc->kind == RGFM_RATIO_MNIST_SVHN) {
+  {
     // gradient path (rgfm_ratio_grad_log_ratio): dL/d(in) of a 3x3 conv is the conv of dL/d(out) with the weights
     // transposed and the taps flipped; of a Linear, the Linear with W^T
     if (hipMalloc(&h->gradw, (h->n_gradw + 4) * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(gradw)");
@@ -1637,7 +1637,63 @@ struct RatioGradRun {
     float* z;
     int C, S;
     bool pooled;
+    float* ab = nullptr;  // GroupNorm encoders: the samples' scale/shift pairs [n][C][2] ...
+    float* mr = nullptr;  // ... and (mean, rstd) of every group [n][8][2]
   };
+
+  // RatioEstimator's ImageEncoder (ratio_estimator.py:67-93) with the conv outputs and their norms' statistics kept
+  void encode_gn(const rgfm_ratio::Encoder& e, const float* img, float* feat, int col0, std::vector<Kept>& kept) {
+    const int F = h->d.feature_dim;
+    int S = e.size;
+    const float* cur = nullptr;
+    int curC = e.in_ch;
+    for (size_t i = 0; i < e.convs.size(); ++i) {
+      const rgfm_ratio::Conv& cv = e.convs[i];
+      const TileGeom g = make_geom(S, S);
+      const int C = cv.w.cout;
+      float* z = ws->f((size_t)n * S * S * C);
+      float* stats = ws->f((size_t)n * g.nparts * C * 2);
+      float* ab = ws->f((size_t)n * C * 2);
+      float* mr = ws->f((size_t)n * 8 * 2);
+      if (!dry) {
+        if (i == 0) {
+          ConvInArgs ci{};
+          ci.x = img, ci.w = h->params + cv.w.w_raw, ci.bias = h->params + cv.w.b;
+          ci.out = z, ci.stats_out = stats, ci.B = n, ci.C0 = C, ci.g = g;
+          launch_conv_in(ci, e.in_ch, s);
+        } else {
+          ConvArgs c{};
+          c.in0 = cur, c.C0 = curC, c.Hin = c.Win = S;
+          c.wpk = h->packed + cv.w.w_pk, c.bias = h->params + cv.w.b;
+          c.out = z, c.stats_out = stats, c.B = n, c.Cout = C, c.g = g;
+          c.halo_px = g.spt * (g.th + 2) * (g.W + 2);
+          launch_conv_mfma(c, CONV_S1, s);
+        }
+        GnFinalizeArgs f{};
+        f.stats0 = stats, f.C0 = C, f.groups = 8;
+        f.gamma = h->params + cv.nw, f.beta = h->params + cv.nb, f.ab = ab, f.mr = mr, f.B = n, f.g = g;
+        launch_gn_finalize(f, s);
+      }
+      Kept k{z, C, S, cv.pool_after};
+      k.ab = ab, k.mr = mr;
+      kept.push_back(k);
+      curC = C;
+      if (cv.pool_after) {
+        float* pl = ws->f((size_t)n * (S / 2) * (S / 2) * C);
+        if (!dry) launch_pool2(z, ab, pl, n, S, S, C, s);
+        cur = pl;
+        S /= 2;
+      } else {
+        cur = z;  // (only the last conv: the average pool applies its norm and SiLU)
+      }
+    }
+    const Kept& last = kept.back();
+    float* pooled = ws->f((size_t)n * curC);
+    if (!dry) {
+      launch_avgpool(cur, last.pooled ? nullptr : last.ab, pooled, n, S * S, curC, s);
+      launch_linear_mfma(pooled, h->params + e.fcw, h->params + e.fcb, feat + col0, n, curC, F, curC, 2 * F, s);
+    }
+  }
 
   float* encode(const rgfm_ratio::Encoder& e, const float* img, float* feat, int col0, std::vector<Kept>& kept) {
     const int F = h->d.feature_dim;
@@ -1705,7 +1761,14 @@ struct RatioGradRun {
       if (i != (int)kept.size() - 1) mode = k.pooled ? 1 : 0;
       else mode = k.pooled ? 3 : 2;  // (SVHN encoder: a max-pool sits between the last conv and the average pool)
       float* gz = ws->f((size_t)n * k.S * k.S * k.C);
-      if (!dry) launch_grad_act(g, k.z, h->bn + cv.bn_scale, gz, n, k.S, k.C, mode, s);
+      if (!dry) {
+        if (k.ab) {  // GroupNorm encoder: SiLU' (and the max-pool routing) at u = a z + b, then the norm's backward in place
+          launch_grad_act_gn(g, k.z, k.ab, gz, n, k.S, k.C, mode, s);
+          launch_gn_bwd(gz, k.z, h->params + cv.nw, k.mr, n, k.S * k.S, k.C, 8, s);
+        } else {
+          launch_grad_act(g, k.z, h->bn + cv.bn_scale, gz, n, k.S, k.C, mode, s);
+        }
+      }
       if (i == 0) {
         if (!dry) launch_conv_bwd_img(gz, h->params + cv.w.w_raw, gimg, n, k.S, k.C, e.in_ch, s);
       } else {
@@ -1730,8 +1793,13 @@ struct RatioGradRun {
     if (!dry) launch_fill_ab_identity(ab1, (size_t)n * 256, s);
     float* feat = ws->f((size_t)n * 2 * F);
     std::vector<Kept> kx, ky;
-    encode(h->ex, x, feat, 0, kx);
-    encode(h->ey, y, feat, F, ky);
+    if (h->d.kind == RGFM_RATIO_MNIST28) {
+      encode_gn(h->ex, x, feat, 0, kx);
+      encode_gn(h->ey, y, feat, F, ky);
+    } else {
+      encode(h->ex, x, feat, 0, kx);
+      encode(h->ey, y, feat, F, ky);
+    }
     std::vector<float*> us, ins{feat};
     float* cur = feat;
     for (const auto& dn : h->hidden) {
@@ -1778,7 +1846,6 @@ size_t ratio_grad_bytes(rgfm_ratio* h, int n) {
 
 extern "C" int rgfm_ratio_grad_workspace_bytes(const rgfm_ratio* h, int n, size_t* bytes) {
   if (!h || !bytes || n < 1) return fail(RGFM_EINVAL, "bad argument");
-  if (h->d.kind != RGFM_RATIO_MNIST_SVHN) return fail(RGFM_EINVAL, "the log-ratio gradient is implemented for RGFM_RATIO_MNIST_SVHN only");
   *bytes = ratio_grad_bytes(const_cast<rgfm_ratio*>(h), n);
   return RGFM_OK;
 }
@@ -1819,8 +1886,12 @@ extern "C" int rgfm_sample_pair_grad(rgfm_unet* hx, rgfm_unet* hy, rgfm_ratio* h
                                      rgfm_stream_t stream) {
   refresh_modes();
   if (!hx || !hy || !hr || !x_inout || !y_inout || !ws) return fail(RGFM_EINVAL, "null argument");
-  if (hx->d.in_channels != 1 || hx->d.img_size != 32 || hy->d.in_channels != 3 || hy->d.img_size != 32)
-    return fail(RGFM_EINVAL, "gradient guidance needs the 1x32x32 + 3x32x32 pair of RatioEstimatorMNISTSVHN");
+  if (hr->d.kind == RGFM_RATIO_MNIST_SVHN) {
+    if (hx->d.in_channels != 1 || hx->d.img_size != 32 || hy->d.in_channels != 3 || hy->d.img_size != 32)
+      return fail(RGFM_EINVAL, "gradient guidance with RatioEstimatorMNISTSVHN needs the 1x32x32 + 3x32x32 pair");
+  } else if (hx->d.in_channels != 1 || hx->d.img_size != 28 || hy->d.in_channels != 1 || hy->d.img_size != 28) {
+    return fail(RGFM_EINVAL, "gradient guidance with RatioEstimator needs the 1x28x28 + 1x28x28 pair");
+  }
   if (batch < 1 || num_steps < 1 || step_begin < 0 || step_end > num_steps || step_begin > step_end)
     return fail(RGFM_EINVAL, "bad step range [%d,%d) of %d", step_begin, step_end, num_steps);
   const int ns = step_end - step_begin;
@@ -1833,7 +1904,7 @@ extern "C" int rgfm_sample_pair_grad(rgfm_unet* hx, rgfm_unet* hy, rgfm_ratio* h
   DevState* ds = cur_dev();
   if (!ds) return fail(RGFM_EINVAL, "no handle has been created on the current device");
   hipStream_t s = (hipStream_t)stream;
-  const int dx = 1024, dy = 3072;
+  const int dx = hx->d.in_channels * hx->d.img_size * hx->d.img_size, dy = hy->d.in_channels * hy->d.img_size * hy->d.img_size;
   Bump b;
   b.base = (char*)ws, b.cap = ws_bytes, b.dry = false;
   float* tx = b.f((size_t)4096 * hx->temb_total);

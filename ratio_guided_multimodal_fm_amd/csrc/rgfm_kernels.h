@@ -175,6 +175,7 @@ struct GnFinalizeArgs {
   int B;
   TileGeom g;
   int rep;              // 0/1: stats0 has g.nparts parts; 4: output of a CONV_T2 launch (4 x g.nparts parts of a 4*HW-pixel map)
+  float* mr;            // optional [B][groups][2]: (mean, rstd) of every group (the norm's backward: launch_gn_bwd)
 };
 
 struct TimeLinear {  // one ResBlock time_mlp Linear: rows [out_off, out_off+cout) of the table
@@ -279,6 +280,9 @@ void launch_fill_ab_identity(float* ab, size_t n_pairs, hipStream_t s);  // (sca
 // (routed to the first maximum of silu(z) in each window); 2: g is [B][C], the gradient of the global average of
 // silu(z); 3: g is [B][C], the gradient of the global average of the 2x2-max-pooled map (modes 2 then 1 in one)
 void launch_grad_act(const float* g, const float* z, const float* scale, float* gz, int B, int S, int C, int mode, hipStream_t s);
+// the GroupNorm encoders (RatioEstimator, 28x28): activation backward with per-sample scale/shift pairs, then the norm's own
+void launch_grad_act_gn(const float* g, const float* z, const float* ab, float* gu, int B, int S, int C, int mode, hipStream_t s);
+void launch_gn_bwd(float* gu, const float* z, const float* gamma, const float* mr, int B, int HW, int C, int groups, hipStream_t s);
 // first conv of an encoder, input gradient as an NCHW image: gimg[b,c,y,x] = sum_co,k w[co,c,k] gz[b, y-ky+1, x-kx+1, co]
 void launch_conv_bwd_img(const float* gz, const float* w, float* gimg, int B, int S, int Co, int cimg, hipStream_t s);
 // y = silu(LayerNorm(u)): gu from gy (wave per row); u is the Linear output kept by the forward

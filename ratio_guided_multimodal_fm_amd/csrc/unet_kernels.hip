@@ -365,6 +365,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const GnFinalizeArgs a
     const double var = m2 / ((double)cpg * npix);
     s_gm[gi] = (float)gm;
     s_rstd[gi] = (float)(1.0 / sqrt(var + 1e-5));
+    if (a.mr) a.mr[((size_t)b * a.groups + gi) * 2] = s_gm[gi], a.mr[((size_t)b * a.groups + gi) * 2 + 1] = s_rstd[gi];
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {

@@ -45,3 +45,13 @@ class RatioEstimator(nn.Module):
         if self.loss_type not in ("disc", "rulsif"):
             raise ValueError(f"Unknown loss_type: {self.loss_type}")
         return self._engine.eval(x, y, "log_ratio")
+
+    def grad_log_ratio(self, x, y):
+        """(d log_ratio/dx, d log_ratio/dy): what ``torch.autograd.grad(self.log_ratio(x, y).sum(), (x, y))`` returns for
+        the reference module in eval mode (reference ``ratio_estimator.py:137-191``; the quantity of the README's
+        "Gradient Log-Ratio" guidance, ``README.md:159-164``).  Hand-written reverse pass on the device through the
+        GroupNorm encoders (``csrc/ratio_grad.hip``: ``gn_bwd_kernel``); the parameters themselves get no gradient."""
+        if self.loss_type not in ("disc", "rulsif"):
+            raise ValueError(f"Unknown loss_type: {self.loss_type}")
+        gx, gy, _ = self._engine.grad_log_ratio(x, y)
+        return gx, gy

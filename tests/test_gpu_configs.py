@@ -242,9 +242,57 @@ def test_ratio_gradient_vs_autograd_fixture_and_oracle(dev, loss):
     ox, oy, olr = O.ratio_grad(br, xb.numpy(), yb.numpy(), loss)
     assert maxdiff(lr.cpu().numpy(), olr) < 1e-5
     assert maxdiff(gx.cpu().numpy(), ox) < 1e-4 * np.abs(ox).max() and maxdiff(gy.cpu().numpy(), oy) < 1e-4 * np.abs(oy).max()
-    r28 = make_module("ratio28", dev)  # GroupNorm encoders: no reverse pass
+    with pytest.raises(_lib.RgfmError):  # the estimator's own image shapes only
+        rr._engine.grad_log_ratio(torch.zeros(1, 1, 28, 28, device=dev), torch.zeros(1, 1, 28, 28, device=dev))
+
+
+@pytest.mark.parametrize("loss", ["disc", "rulsif"])
+def test_ratio28_gradient_vs_autograd_fixture_and_oracle(dev, loss):
+    """The same for the 28x28 RatioEstimator (GroupNorm encoders, ratio_estimator.py:34-191; 28 -> 14 -> 7 -> 3 with a
+    floor pooling that leaves the 7x7 map's last row and column without gradient): HIP reverse pass
+    (grad_act_kernel<true> + gn_bwd_kernel + the transposed-weight convs) against torch.autograd.grad on the reference
+    module (tests/golden/ratio_grad28.npz) and against the oracle on a ragged batch."""
+    from ratio_guided_multimodal_fm_amd import models as M
+    from ratio_guided_multimodal_fm_amd.synth import load_synth
+    g = golden("ratio_grad28")
+    rr = load_synth(M.RatioEstimator(loss_type=loss), 15).eval().to(dev)
+    gen = torch.Generator().manual_seed(86)
+    x = torch.randn(3, 1, 28, 28, generator=gen)
+    y = torch.randn(3, 1, 28, 28, generator=gen)
+    for tag, sc in (("n", 1.0), ("s", 0.3)):
+        gx, gy, lr = rr._engine.grad_log_ratio((x * sc).to(dev), (y * sc).to(dev))
+        rx, ry = g[f"{loss}_{tag}_gx"], g[f"{loss}_{tag}_gy"]
+        assert maxdiff(lr.cpu().numpy(), g[f"{loss}_{tag}_lr"]) < 1e-5
+        assert maxdiff(gx.cpu().numpy(), rx) < 1e-4 * np.abs(rx).max(), (tag, maxdiff(gx.cpu().numpy(), rx))
+        assert maxdiff(gy.cpu().numpy(), ry) < 1e-4 * np.abs(ry).max(), (tag, maxdiff(gy.cpu().numpy(), ry))
+        a, b = rr.grad_log_ratio((x * sc).to(dev), (y * sc).to(dev))  # the module-level API
+        assert torch.equal(a, gx) and torch.equal(b, gy)
+    _, br = oracle_net("ratio28")
+    xb = torch.randn(37, 1, 28, 28, generator=gen)
+    yb = torch.randn(37, 1, 28, 28, generator=gen)
+    gx, gy, lr = rr._engine.grad_log_ratio(xb.to(dev), yb.to(dev))
+    ox, oy, olr = O.ratio_grad(br, xb.numpy(), yb.numpy(), loss, kind="mnist28")
+    assert maxdiff(lr.cpu().numpy(), olr) < 1e-5
+    assert maxdiff(gx.cpu().numpy(), ox) < 1e-4 * np.abs(ox).max() and maxdiff(gy.cpu().numpy(), oy) < 1e-4 * np.abs(oy).max()
     with pytest.raises(_lib.RgfmError):
-        r28._engine.grad_log_ratio(torch.zeros(1, 1, 28, 28, device=dev), torch.zeros(1, 1, 28, 28, device=dev))
+        rr._engine.grad_log_ratio(torch.zeros(1, 1, 32, 32, device=dev), torch.zeros(1, 3, 32, 32, device=dev))
+
+
+def test_grad_log_ratio_sampler28_vs_oracle(dev):
+    """guidance_method='grad_log_ratio' on the 28x28 pair (two FlowMatchingUNet nets + RatioEstimator) against the
+    oracle's composition (parity unpinned for the loop, pinned for the gradient, as for the 32x32 pair)."""
+    from ratio_guided_multimodal_fm_amd.utils.flow_utils import paired_sampler
+    fx, fy, rr = make_module("unet28", dev), make_module("unet28_y", dev), make_module("ratio28", dev)
+    noise = paired_noise(34, 5, 0, (1, 28, 28), (1, 28, 28))
+    S, gamma = 6, 2.0
+    xs, ys = paired_sampler(fx, fy, rr, "grad_log_ratio", gamma, 5, S, dev, 4, (1, 28, 28), (1, 28, 28), noise=noise, verbose=False)
+    dx, bx = oracle_net("unet28")
+    dy, by = oracle_net("unet28_y")
+    _, br = oracle_net("ratio28")
+    ox, oy = O.sample_pair_grad(dx, bx, dy, by, br, noise[0].numpy(), noise[1].numpy(), S, gamma, kind="mnist28")
+    assert maxdiff(xs.cpu().numpy(), ox) < TOL_SAMPLER and maxdiff(ys.cpu().numpy(), oy) < TOL_SAMPLER
+    xn, yn = paired_sampler(fx, fy, None, "none", 0.0, 5, S, dev, 4, (1, 28, 28), (1, 28, 28), noise=noise, verbose=False)
+    assert maxdiff(xs.cpu().numpy(), xn.cpu().numpy()) > 1e-5  # (the guidance does something)
 
 
 def test_grad_log_ratio_sampler_vs_oracle(dev):
