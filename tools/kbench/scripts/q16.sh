@@ -1,0 +1,10 @@
+#!/bin/bash
+# A/B of two kbench builds on the Cout = 32 layers of the MNIST net (tile-stream kernel, {1,1} cut): q16.sh OLD NEW
+export REPS=${REPS:-1000}
+OLD=${1:-tools/kbench/conv_bench_old}; NEW=${2:-tools/kbench/conv_bench}
+for B in 256 512; do
+for a in "32 32 32 0 1" "32 32 32 0 0" "32 96 32 0 0" "32 64 32 0 0" "32 32 32 0 2"; do
+  echo -n "old: "; RGFM_KB_R=64 timeout -k 10 120 $OLD $a $B hx2q | tail -1 || exit 1
+  echo -n "new: "; RGFM_KB_R=64 timeout -k 10 120 $NEW $a $B hx2q || exit 1
+done
+done
