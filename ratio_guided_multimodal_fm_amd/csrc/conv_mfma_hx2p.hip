@@ -864,24 +864,26 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, (RGFM_HX2P_QEXP
   int lane_e = lane;
   asm volatile("" : "+v"(lane_e));
   const int l31 = lane_e & 31, h = lane_e >> 5;
+  // folded eval-mode BatchNorm (+ SiLU) of the ratio estimators' encoders, as conv_mfma.hip.  ONCE, in front of the two
+  // instantiations of the epilogue: inside them (two copies) it cost the 128-channel instantiations 16-20 bytes of scratch
+  if (a.ep_scale) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float es = a.ep_scale[n0 + nt * 32 + l31], eh = a.ep_shift[n0 + nt * 32 + l31];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[mt][nt][r] * es + eh;
+          acc[mt][nt][r] = a.ep_nosilu ? v : silu_f(v);
+        }
+    }
+  }
   // Two instantiations of the same epilogue: FULL (every pixel of this wave's 64-pixel segment is valid -- all
   // waves of all interior tiles) has no per-element predicates, which are a third of its instructions.
   auto epilogue = [&](auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
     unsigned vmask[2] = {0u, 0u};
-    if (a.ep_scale) {  // folded eval-mode BatchNorm (+ SiLU) of the ratio estimators' encoders, as conv_mfma.hip
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const float es = a.ep_scale[n0 + nt * 32 + l31], eh = a.ep_shift[n0 + nt * 32 + l31];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float v = acc[mt][nt][r] * es + eh;
-            acc[mt][nt][r] = a.ep_nosilu ? v : silu_f(v);
-          }
-      }
-    }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
