@@ -951,8 +951,14 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, (RGFM_HX2P_QEXP
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (FULL || (vmask[mt] & (1u << r))) m = fmaxf(m, fabsf(acc[mt][nt][r]));
+          for (int r = 0; r < 16; r += 2) {  // (v_max3_f32 with |.| modifiers: one instruction per two values)
+            if (FULL) {
+              m = hx_absmax3(acc[mt][nt][r], acc[mt][nt][r + 1], m);
+            } else {
+              if (vmask[mt] & (1u << r)) m = fmaxf(m, fabsf(acc[mt][nt][r]));
+              if (vmask[mt] & (2u << r)) m = fmaxf(m, fabsf(acc[mt][nt][r + 1]));
+            }
+          }
       hx_small_flag(a.range_flag, m);
     }
   };

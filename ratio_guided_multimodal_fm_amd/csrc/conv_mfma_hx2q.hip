@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256 * NG, (NG == 2 && NT == 1) ? 4 : 2) void conv_m
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(acc[mt][nt][r]));
+          for (int r = 0; r < 16; r += 2) m = hx_absmax3(acc[mt][nt][r], acc[mt][nt][r + 1], m);
       hx_small_flag(ke.range_flag, m);
     }
     QPROF_T(tt3);

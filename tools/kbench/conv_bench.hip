@@ -127,6 +127,7 @@ int main(int argc, char** argv) {
   a.bias = dev_rand(Cout, 0.1f, 4);
   a.temb = dev_rand(Cout, 0.1f, 5), a.temb_stride = Cout;
   a.res_mode = res;
+  if (getenv("RGFM_KB_SC")) a.small_check = atoi(getenv("RGFM_KB_SC"));  // the output's low-range check (ConvArgs::small_check)
   int skipk = 0;
   if (res == 1) a.res0 = dev_rand((size_t)B * S * S * Cout, 1.f, 6), a.R0 = Cout;
   if (res == 2) {
