@@ -499,6 +499,18 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2_kernel(const ConvArgs a,
   auto epilogue = [&](auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
     unsigned vmask[2] = {0u, 0u};
+    // ConvArgs::small_check: the output's low range.  For full segments HERE, while nothing but the accumulators is live
+    // (behind the stores and the statistics it costs registers: conv_mfma_hx2q.hip)
+    if (FULL && a.small_check && a.range_flag) {
+      float m = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) m = hx_absmax3(acc[mt][nt][r], acc[mt][nt][r + 1], m);
+      hx_small_flag(a.range_flag, m);
+    }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -559,21 +571,15 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2_kernel(const ConvArgs a,
       }
       if (a.fin_ab && sample_ok) fin_arrive(a, bw, lane_e, nparts, MODE == CONV_T2);
     }
-    if (a.small_check && a.range_flag) {  // (ConvArgs::small_check: the output's low range)
+    if (!FULL && a.small_check && a.range_flag) {  // (edge tiles: only the valid pixels count)
       float m = 0.f;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int r = 0; r < 16; r += 2) {  // (v_max3_f32 with |.| modifiers: one instruction per two values)
-            if (FULL) {
-              m = hx_absmax3(acc[mt][nt][r], acc[mt][nt][r + 1], m);
-            } else {
-              if (vmask[mt] & (1u << r)) m = fmaxf(m, fabsf(acc[mt][nt][r]));
-              if (vmask[mt] & (2u << r)) m = fmaxf(m, fabsf(acc[mt][nt][r + 1]));
-            }
-          }
+          for (int r = 0; r < 16; ++r)
+            if (vmask[mt] & (1u << r)) m = fmaxf(m, fabsf(acc[mt][nt][r]));
       hx_small_flag(a.range_flag, m);
     }
   };

@@ -560,6 +560,18 @@ __global__ __launch_bounds__(256 * NG, (NG == 2 && NT == 1) ? 4 : 2) void conv_m
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc[mt][nt] * qinv;
     }
+    // (ConvArgs::small_check: the output's low range.  HERE, while nothing but the accumulators is live: behind the stores
+    // and the statistics it cost the 128-register cut 33 more spilled registers)
+    if (ke.small_check && ke.range_flag) {
+      float m = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) m = hx_absmax3(acc[mt][nt][r], acc[mt][nt][r + 1], m);
+      hx_small_flag(ke.range_flag, m);
+    }
     // ---------------------------------------------------------------- epilogue: every pixel of the tile is valid
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -594,16 +606,6 @@ __global__ __launch_bounds__(256 * NG, (NG == 2 && NT == 1) ? 4 : 2) void conv_m
         if (hp_e == 0) store_stats(ke, ke.stats_out + (((size_t)tb * nparts + part) * ke.Cout + ch_e + nt * 32) * 2, mean, m2);
       }
       if (ke.fin_ab) fin_arrive(ke, tb, lane_e, nparts, false);
-    }
-    if (ke.small_check && ke.range_flag) {  // (ConvArgs::small_check: the output's low range)
-      float m = 0.f;
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int r = 0; r < 16; r += 2) m = hx_absmax3(acc[mt][nt][r], acc[mt][nt][r + 1], m);
-      hx_small_flag(ke.range_flag, m);
     }
     QPROF_T(tt3);
     QPROF_ACC(0, tt0, tt1);
