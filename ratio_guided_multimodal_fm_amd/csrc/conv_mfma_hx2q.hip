@@ -331,7 +331,24 @@ __global__ __launch_bounds__(256 * NG, (NG == 2 && NT == 1) ? 4 : 2) void conv_m
     else HX2Q_WDMA_WAIT(6);
   }
 
+  // the scales and (when every row shares the time value: the samplers) the per-channel additive term are the same for
+  // every tile of the workgroup: loaded ONCE (scalar registers / one VGPR per column) -- re-derived per tile they were two
+  // to three dependent memory round trips in front of every tile's first MFMA and behind its last
+  // (NG == 1 only -- the cut with registers to spare: +1 ... 2 % on its layers; in the 128-register cut the extra live
+  // values spill and the layers lose 2 ... 3 %: tools/kbench/scripts/q19.sh)
+  constexpr bool HOIST = NG == 1;
   const float qmain = a.hq[0];
+  const float qinv_all = HOIST ? (SKIP ? a.hq_skip[1] : a.hq[1]) : 0.f;
+  const bool add_const = HOIST && !(a.temb && a.temb_per_row);
+  float add_all[NT];
+#pragma unroll
+  for (int nt = 0; HOIST && nt < NT; ++nt) {
+    const int c = cb * CB + grp * 32 * NT + l31 + nt * 32;
+    float v = a.bias[c];
+    if (SKIP) v += a.skip_bias[c];
+    if (a.temb && !a.temb_per_row) v += a.temb[(a.step_ptr ? (size_t)*a.step_ptr : 0) * a.temb_stride + c];
+    add_all[nt] = v * qmain;
+  }
   f32x16 acc[2][NT];
   // one tap (kernel column KX of the halo row at sArow): 6 fragment reads, 6 MFMAs (a_l w_h, a_h w_l, a_h w_h per tile)
   auto tap = [&](const char* sArow, const char* sBt, int o0) {
@@ -417,11 +434,15 @@ __global__ __launch_bounds__(256 * NG, (NG == 2 && NT == 1) ? 4 : 2) void conv_m
       float add0[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const int c = ch_b + nt * 32;
-        float v = ka.bias[c];
-        if (SKIP) v += ka.skip_bias[c];
-        if (ka.temb) v += ka.temb[((size_t)(ka.temb_per_row ? tb : 0) + (ka.step_ptr ? (size_t)*ka.step_ptr : 0)) * ka.temb_stride + c];
-        add0[nt] = v * qmain;
+        if (add_const) {
+          add0[nt] = add_all[nt];
+        } else {  // (a time value per row -- rgfm_unet_forward --, or the 128-register cut)
+          const int c = ch_b + nt * 32;
+          float v = ka.bias[c];
+          if (SKIP) v += ka.skip_bias[c];
+          if (ka.temb) v += ka.temb[((size_t)(ka.temb_per_row ? tb : 0) + (ka.step_ptr ? (size_t)*ka.step_ptr : 0)) * ka.temb_stride + c];
+          add0[nt] = v * qmain;
+        }
       }
       if (!SKIP && ka.res_mode == 1) {
 #pragma unroll
@@ -554,7 +575,7 @@ __global__ __launch_bounds__(256 * NG, (NG == 2 && NT == 1) ? 4 : 2) void conv_m
     const int ch_e = cb * CB + (tid_e >> 8) * 32 * NT + l31_e;
     const ConvArgs& ke = *kp;
     {
-      const float qinv = SKIP ? ke.hq_skip[1] : ke.hq[1];
+      const float qinv = HOIST ? qinv_all : (SKIP ? ke.hq_skip[1] : ke.hq[1]);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
