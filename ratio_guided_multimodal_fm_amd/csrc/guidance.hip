@@ -65,10 +65,10 @@ __global__ __launch_bounds__(256) void guid_logp_kernel(const GuidanceArgs a_in)
   for (int j = 0; j < 6; ++j) {
     const int it = tid + 256 * j;
     const bool isx = it < 512;
-    const int row = isx ? it >> 4 : (it - 512) >> 4, q = it & 15;
+    const int row = isx ? it >> 4 : (it - 512) >> 4;
     const int grow = isx ? bb + row : ib + row;
     ok[j] = isx ? grow < a.B : grow < a.N;
-    src[j] = (isx ? X : M) + (size_t)(ok[j] ? grow : 0) * D + q * 4;
+    src[j] = (isx ? X : M) + (size_t)(ok[j] ? grow : 0) * D;  // (the row; the float4 inside it: fetch)
   }
   f32x4 rv[6];
   auto fetch = [&](int d0) {
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void guid_logp_kernel(const GuidanceArgs a_in)
     for (int j = 0; j < 6; ++j) {
       const int d = d0 + (tid & 15) * 4;
       const bool in = ok[j] && d < dend;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(src[j] + (in ? d0 : dbeg));  // (clamped: always a valid address)
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src[j] + (in ? d : 0));  // (clamped to the row's first float4: always valid)
       rv[j] = in ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };

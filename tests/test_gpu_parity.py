@@ -149,7 +149,9 @@ def test_ratio(dev, tag, gname, sx, sy):
 
 
 @pytest.mark.parametrize("B,N,sx,sy", [(6, 12, (1, 32, 32), (3, 32, 32)), (33, 70, (1, 28, 28), (1, 28, 28)),
-                                       (1, 1, (1, 32, 32), (3, 32, 32))])
+                                       (1, 1, (1, 32, 32), (3, 32, 32)),
+                                       # a D-slice of 8 elements (520 = 512 + 8) and a modality shorter than one chunk
+                                       (5, 9, (1, 2, 260), (3, 4, 4))])
 def test_guidance_block_vs_oracle(dev, B, N, sx, sy):
     """Random (x, y) against a random MC set is the WORST conditioning for the weights:
     l ~ -2000 carries an fp32 ulp of 2.4e-4, so weights agree to ~1e-3 relative; the
