@@ -46,7 +46,7 @@ PEAK_16BIT_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / f16 MFMA
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured with a float4 copy)
 ARITHMETIC = {
     "hx2": "f32 emulated on the f16 matrix cores: operands as 2 scaled fp16 planes (22-bit significands), 3 of the 4 plane "
-           "products per fp32 product, fp32 accumulate; range-guarded with a split-bf16 fallback (DESIGN.md section 4)",
+           "products per fp32 product, fp32 accumulate; range-guarded on both sides: a call whose activations leave the window is repeated on split-bf16 (high side) or on the fp32 MFMA (low side) (DESIGN.md sections 2 and 4)",
     "bx3": "f32 emulated on the bf16 matrix cores: operands as 3 exact bf16 planes (24-bit significands), 6 products per "
            "fp32 product, fp32 accumulate",
     "f32": "f32 on the matrix cores: v_mfma_f32_32x32x2_f32",
