@@ -199,6 +199,7 @@ struct ConvW {  // one packed conv
   size_t w_pk = 0;          // offset into the packed buffer
   size_t w_bx3 = 0;         // offset (bf16 elements) into the 3-plane bf16 buffer of conv_mfma_bx3.hip
   size_t w_hx2 = 0;         // offset (fp16 elements) into the 2-plane fp16 buffer of conv_mfma_hx2.hip
+  size_t w_hx9 = 0;         // stride-2 convs: offset of the plain nine-tap fp16 image (conv_mfma_hx2s.hip), + 1 (0: none)
   int hq = 0;               // index of the conv's scale record {q, 1/q, s_w, eligible} in the handle's hq array
   bool hx_ok = false;       // weights inside the fp16 path's range (set after packing)
   int cin = 0, cout = 0, taps = 9;
@@ -305,7 +306,7 @@ int ensure_init() {
   DevState& d = g_dev[dev];
   if (!d.init) {
     if (conv_mfma_init() != 0 || conv_bx3_init() != 0 || conv_hx2_init() != 0 || conv_hx2p_init() != 0 || conv_hx2q_init() != 0 ||
-        guid_apply_init() != 0)
+        conv_hx2s_init() != 0 || guid_apply_init() != 0)
       return fail(RGFM_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, dev) == hipSuccess) d.num_cus = p.multiProcessorCount;
@@ -323,7 +324,8 @@ int ensure_init() {
 }
 
 void launch_conv(const ConvArgs& c, int mode, hipStream_t s) {
-  if (g_modes.conv == CONV_ARITH_HX2 && g_modes.pipelined && g_modes.quad && conv_hx2q_supported(c, mode)) launch_conv_hx2q(c, mode, s);
+  if (g_modes.conv == CONV_ARITH_HX2 && g_modes.pipelined && conv_hx2s_supported(c, mode)) launch_conv_hx2s(c, s);
+  else if (g_modes.conv == CONV_ARITH_HX2 && g_modes.pipelined && g_modes.quad && conv_hx2q_supported(c, mode)) launch_conv_hx2q(c, mode, s);
   else if (g_modes.conv == CONV_ARITH_HX2 && g_modes.pipelined && conv_hx2p_supported(c, mode)) launch_conv_hx2p(c, mode, s);
   else if (g_modes.conv == CONV_ARITH_HX2 && conv_hx2_supported(c, mode)) launch_conv_hx2(c, mode, s);
   else if (g_modes.conv != CONV_ARITH_F32 && conv_bx3_supported(c, mode)) launch_conv_bx3(c, mode, s);
@@ -445,7 +447,11 @@ size_t plan_unet(const rgfm_unet_desc& d, rgfm_unet* h) {
       skips.push_back(ch);
     }
   }
-  for (int dc : down_ch) down.push_back(conv(dc, dc, 9));
+  for (int dc : down_ch) {
+    ConvW w = conv(dc, dc, 9);
+    w.w_hx9 = ph.take((size_t)dc * dc * 9 * 2) + 1;  // (the Downsample convs twice: phase-major and plain)
+    down.push_back(w);
+  }
   mid.push_back(res(ch, ch));
   mid.push_back(res(ch, ch));
   for (int l = d.num_levels - 1; l >= 0; --l) {
@@ -514,6 +520,7 @@ int read_hx_flags(const float* hq_dev, int n, std::vector<ConvW*>& convs, hipStr
 void fill_hx2(ConvArgs& c, const unsigned short* packedh, const float* hq, unsigned* flag, const ConvW& w, const ConvW* sk) {
   if (!w.hx_ok || (sk && !sk->hx_ok)) return;
   c.wpkh = packedh + w.w_hx2, c.hq = hq + 4 * w.hq, c.range_flag = flag;
+  if (w.w_hx9) c.wpkh9 = packedh + (w.w_hx9 - 1);
   if (sk) c.wskiph = packedh + sk->w_hx2, c.hq_skip = hq + 4 * sk->hq;
 }
 
@@ -801,6 +808,8 @@ extern "C" int rgfm_unet_create(const rgfm_unet_desc* desc, const float* params_
     }
   for (ConvW* w : all) pack_one(h, *w, CONV_S1, s);
   for (ConvW& w : h->down) pack_one(h, w, CONV_S2, s), all.push_back(&w);  // stride-2 convs: phase-ordered weights
+  for (ConvW& w : h->down)  // ... and once more in plain tap order (same scale record: same weights)
+    launch_pack_conv_hx2(h->params + w.w_raw, h->packedh + (w.w_hx9 - 1), h->hq + 4 * w.hq, w.cout, w.cin, 9, CONV_S1, s);
   for (ConvW& w : h->up) pack_one(h, w, CONV_S1, s), all.push_back(&w);
   if (read_hx_flags(h->hq, h->n_hq, all, s) != RGFM_OK) return bail(RGFM_EHIP, "reading the fp16 scale records failed");
   {

@@ -95,6 +95,7 @@ struct ConvArgs {
   // when a staged activation leaves the fp16 range (the host then repeats the call on the split-bf16 kernel)
   const void* wpkh;
   const void* wskiph;
+  const void* wpkh9;  // stride-2 convs: the weights once more as the plain nine-tap image (conv_mfma_hx2s.hip), or null
   const float* hq;
   const float* hq_skip;
   unsigned* range_flag;
@@ -228,6 +229,11 @@ void launch_conv_hx2p(const ConvArgs& a, int mode, hipStream_t s);
 // rasters with Cout % 64 == 0 and a consumer-side input norm; bit-identical results
 bool conv_hx2q_supported(const ConvArgs& a, int mode);
 int conv_hx2q_init();
+// conv_mfma_hx2s.hip: the Downsample convs (stride 2, raw input) with a chunk's four parity planes staged together
+bool conv_hx2s_supported(const ConvArgs& a, int mode);
+int conv_hx2s_init();
+void conv_hx2s_set(int on);
+void launch_conv_hx2s(const ConvArgs& a, hipStream_t s);
 void conv_hx2q_set_min(int v);  // launches with fewer workgroups than this stay on conv_mfma_hx2p_kernel (0: never used)
 void conv_hx2q_set_target(int v);  // workgroups a launch is cut into when it has the tiles (two per CU)
 void conv_hx2q_set_tpw(int v);     // tools/kbench: force the tiles per workgroup

@@ -1,5 +1,6 @@
 // Single-layer benchmark of the conv kernels (development tool; not part of the library).
-//   conv_bench <S> <Cin> <Cout> [mode 0|2] [res 0|1|2] [B] [which: bx3|f32|hx2|hx2p|hx2q]
+//   conv_bench <S> <Cin> <Cout> [mode 0|1|2] [res 0|1|2] [B] [which: bx3|f32|hx2|hx2p|hx2q|hx2s]
+//   (mode 1: the stride-2 conv of a Downsample -- S is the OUTPUT size, the input is raw: hx2 or hx2s)
 // Every run also checks the selected kernel against the exact-fp32 MFMA kernel on the same data.
 // Builds one ConvArgs with random NHWC input / packed weights, launches it 20x, prints us and
 // fp32-equivalent TFLOP/s; with -DRGFM_BX3_PROF also the per-phase cycle counts of the bx3w kernel.
@@ -15,6 +16,7 @@
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2.hip"
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2p.hip"
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2q.hip"
+#include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2s.hip"
 #include "../../ratio_guided_multimodal_fm_amd/csrc/unet_kernels.hip"
 
 using namespace rgfm;
@@ -57,7 +59,8 @@ int main(int argc, char** argv) {
   const bool hx2 = argc > 7 && strcmp(argv[7], "hx2") == 0;
   const bool hx2p = argc > 7 && strcmp(argv[7], "hx2p") == 0;
   const bool hx2q = argc > 7 && strcmp(argv[7], "hx2q") == 0;
-  const int Sin = mode == CONV_UP2 ? S / 2 : S;
+  const bool hx2s = argc > 7 && strcmp(argv[7], "hx2s") == 0;
+  const int Sin = mode == CONV_UP2 ? S / 2 : (mode == CONV_S2 ? 2 * S : S);
   const int nt = Cout % 64 == 0 ? 2 : 1;
   CK(hipSetDevice(0));
   conv_mfma_init();
@@ -65,6 +68,7 @@ int main(int argc, char** argv) {
   conv_hx2_init();
   conv_hx2p_init();
   conv_hx2q_init();
+  conv_hx2s_init();
   if (getenv("RGFM_HX2Q_MIN")) conv_hx2q_set_min(atoi(getenv("RGFM_HX2Q_MIN")));
   if (getenv("RGFM_HX2Q_TPW")) conv_hx2q_set_tpw(atoi(getenv("RGFM_HX2Q_TPW")));
   conv_hx2q_set_all(1);
@@ -118,14 +122,22 @@ int main(int argc, char** argv) {
   hipMalloc(&wh, (size_t)Cout * Cin * 9 * 4);
   float* hq;
   hipMalloc(&hq, 8 * sizeof(float));
-  launch_pack_conv_hx2(w, wh, hq, Cout, Cin, 9, CONV_S1, 0);
+  launch_pack_conv_hx2(w, wh, hq, Cout, Cin, 9, mode == CONV_S2 ? CONV_S2 : CONV_S1, 0);
   a.wpkh = wh, a.hq = hq;
+  if (mode == CONV_S2) {  // the plain nine-tap image once more (conv_mfma_hx2s.hip)
+    void* wh9;
+    hipMalloc(&wh9, (size_t)Cout * Cin * 9 * 4);
+    launch_pack_conv_hx2(w, wh9, hq, Cout, Cin, 9, CONV_S1, 0);
+    a.wpkh9 = wh9;
+    a.ab = nullptr;  // (raw input)
+  }
   unsigned* flag;
   hipMalloc(&flag, 4);
   hipMemset(flag, 0, 4);
   a.range_flag = flag;
   a.bias = dev_rand(Cout, 0.1f, 4);
   a.temb = dev_rand(Cout, 0.1f, 5), a.temb_stride = Cout;
+  if (mode == CONV_S2) a.temb = nullptr;  // (a Downsample has no time term)
   a.res_mode = res;
   if (getenv("RGFM_KB_SC")) a.small_check = atoi(getenv("RGFM_KB_SC"));  // the output's low-range check (ConvArgs::small_check)
   int skipk = 0;
@@ -161,17 +173,20 @@ int main(int argc, char** argv) {
   ap.ab = nullptr, ap.gn_stats0 = gstats, ap.gn_gamma = ggamma, ap.gn_beta = gbeta, ap.gn_nparts0 = gin.nparts, ap.gn_g = gin;
   if (hx2p && !conv_hx2p_supported(ap, mode)) { printf("hx2p: unsupported shape\n"); return 1; }
   if (hx2q && !conv_hx2q_supported(ap, mode)) { printf("hx2q: unsupported shape\n"); return 1; }
+  if (hx2s && !conv_hx2s_supported(a, mode)) { printf("hx2s: unsupported shape\n"); return 1; }
   auto launch = [&]() {
     if (f32) launch_conv_mfma(a, mode, 0);
     else if (hx2) launch_conv_hx2(a, mode, 0);
     else if (hx2p) launch_conv_hx2p(ap, mode, 0);
     else if (hx2q) launch_conv_hx2q(ap, mode, 0);
+    else if (hx2s) launch_conv_hx2s(a, 0);
     else launch_conv_bx3(a, mode, 0);
   };
   {  // reference: the exact-fp32 MFMA kernel on the same data
     const size_t no = (size_t)B * S * S * Cout, ns = (size_t)B * a.g.nparts * Cout * 2;
     std::vector<float> ref(no), got(no), sref(ns), sgot(ns);
-    launch_conv_mfma(a, mode, 0);
+    if (mode == CONV_S2) launch_conv_hx2(a, mode, 0);  // (stride 2: the reference is conv_mfma_hx2_kernel, itself pinned by the library's parity tests)
+    else launch_conv_mfma(a, mode, 0);
     CK(hipDeviceSynchronize());
     CK(hipGetLastError());
     hipMemcpy(ref.data(), out, no * 4, hipMemcpyDeviceToHost);
@@ -224,7 +239,7 @@ int main(int argc, char** argv) {
   float ms;
   hipEventElapsedTime(&ms, e0, e1);
   const double us = ms * 1e3 / reps;
-  printf("%s S=%d Cin=%d Cout=%d mode=%d res=%d B=%d: %8.1f us  %6.1f TFLOP/s (fp32-equivalent)\n", f32 ? "f32" : (hx2 ? "hx2" : (hx2p ? "hx2p" : (hx2q ? "hx2q" : "bx3"))), S, Cin,
+  printf("%s S=%d Cin=%d Cout=%d mode=%d res=%d B=%d: %8.1f us  %6.1f TFLOP/s (fp32-equivalent)\n", f32 ? "f32" : (hx2 ? "hx2" : (hx2p ? "hx2p" : (hx2q ? "hx2q" : (hx2s ? "hx2s" : "bx3")))), S, Cin,
          Cout, mode, res, B, us, flops / us / 1e6);
 #ifdef RGFM_HX2Q_PROF
   if (hx2q) {
