@@ -110,7 +110,7 @@ def kernel_sources_sha():
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "ratio_guided_multimodal_fm_amd", "csrc")
-    for name in ("conv_hx2_common.h", "conv_mfma_hx2.hip", "conv_mfma_hx2p.hip", "conv_mfma_hx2q.hip", "conv_mfma_hx2s.hip", "conv_mfma_bx3.hip",
+    for name in ("conv_hx2_common.h", "conv_mfma_hx2.hip", "conv_mfma_hx2p.hip", "conv_mfma_hx2q.hip", "conv_mfma_hx2s.hip", "conv_mfma_hx2c.hip", "conv_mfma_bx3.hip",
                  "conv_mfma.hip", "rgfm_device.h", "rgfm_kernels.h"):
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(f.read())

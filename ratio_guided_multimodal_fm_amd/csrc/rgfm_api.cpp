@@ -230,14 +230,15 @@ bool on_gfx950() {
 //   RGFM_OVERLAP=0   both velocity nets of a step on the caller's stream;
 //   RGFM_FUSE_FIN=0  separate gn_finalize launches instead of the producer-side finalize;
 //   RGFM_GN=table    every GroupNorm finalized into a scale/shift array instead of the consumer-side prologue;
-//   RGFM_HX2P=0, RGFM_HX2Q=0, RGFM_HX2S=0, RGFM_GRAPH=1: A/B switches of the pipelined fp16 kernel, its
-//               four-waves-per-SIMD version, the stride-2 kernel and the hipGraph replay.
+//   RGFM_HX2P=0, RGFM_HX2Q=0, RGFM_HX2S=0, RGFM_HX2C=0, RGFM_GRAPH=1: A/B switches of the pipelined fp16 kernel, its
+//               four-waves-per-SIMD version, the stride-2 kernel, the 8x8-level kernel and the hipGraph replay.
 enum { CONV_ARITH_HX2 = 0, CONV_ARITH_BX3 = 1, CONV_ARITH_F32 = 2 };
 struct Modes {
   int conv = CONV_ARITH_HX2;
   bool overlap = true, fuse_fin = true, gn_consumer = true;
   bool pipelined = true;  // RGFM_HX2P=0: the fp16 convs on conv_mfma_hx2_kernel only (A/B switch)
   bool quad = true;       // RGFM_HX2Q=0: no four-waves-per-SIMD workgroups (conv_mfma_hx2q.hip; A/B switch, bit-identical)
+  bool c8 = true;         // RGFM_HX2C=0: the 8x8 level on conv_mfma_hx2p_kernel (A/B switch)
   bool s2 = true;         // RGFM_HX2S=0: the Downsample convs on conv_mfma_hx2_kernel<*, CONV_S2, *> (A/B switch; same to 1e-6)
   bool graph = false;     // RGFM_GRAPH=1: the guided steps of the paired U-Net loop replayed from one captured hipGraph
                           // (bit-identical; measured 0.995-1.002x of the kernel-by-kernel path: the host is not the bottleneck)
@@ -260,6 +261,8 @@ void refresh_modes() {
   m.quad = !(e && e[0] == '0');
   e = getenv("RGFM_HX2S");
   m.s2 = !(e && e[0] == '0');
+  e = getenv("RGFM_HX2C");
+  m.c8 = !(e && e[0] == '0');
   e = getenv("RGFM_GRAPH");
   m.graph = e && e[0] == '1';
   g_modes = m;
@@ -309,7 +312,7 @@ int ensure_init() {
   DevState& d = g_dev[dev];
   if (!d.init) {
     if (conv_mfma_init() != 0 || conv_bx3_init() != 0 || conv_hx2_init() != 0 || conv_hx2p_init() != 0 || conv_hx2q_init() != 0 ||
-        conv_hx2s_init() != 0 || guid_apply_init() != 0)
+        conv_hx2s_init() != 0 || conv_hx2c_init() != 0 || guid_apply_init() != 0)
       return fail(RGFM_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, dev) == hipSuccess) d.num_cus = p.multiProcessorCount;
@@ -328,6 +331,7 @@ int ensure_init() {
 
 void launch_conv(const ConvArgs& c, int mode, hipStream_t s) {
   if (g_modes.conv == CONV_ARITH_HX2 && g_modes.pipelined && g_modes.s2 && conv_hx2s_supported(c, mode)) launch_conv_hx2s(c, s);
+  else if (g_modes.conv == CONV_ARITH_HX2 && g_modes.pipelined && g_modes.c8 && conv_hx2c_supported(c, mode)) launch_conv_hx2c(c, s);
   else if (g_modes.conv == CONV_ARITH_HX2 && g_modes.pipelined && g_modes.quad && conv_hx2q_supported(c, mode)) launch_conv_hx2q(c, mode, s);
   else if (g_modes.conv == CONV_ARITH_HX2 && g_modes.pipelined && conv_hx2p_supported(c, mode)) launch_conv_hx2p(c, mode, s);
   else if (g_modes.conv == CONV_ARITH_HX2 && conv_hx2_supported(c, mode)) launch_conv_hx2(c, mode, s);

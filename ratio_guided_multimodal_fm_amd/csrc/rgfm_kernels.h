@@ -234,6 +234,12 @@ bool conv_hx2s_supported(const ConvArgs& a, int mode);
 int conv_hx2s_init();
 void conv_hx2s_set(int on);
 void launch_conv_hx2s(const ConvArgs& a, hipStream_t s);
+// conv_mfma_hx2c.hip: the stride-1 convs of the 8x8 level, one barrier per chunk (cut for the workgroup's serial chain)
+bool conv_hx2c_supported(const ConvArgs& a, int mode);
+int conv_hx2c_init();
+void conv_hx2c_set(int on);
+void conv_hx2c_set_all(int on);
+void launch_conv_hx2c(const ConvArgs& a, hipStream_t s);
 void conv_hx2q_set_min(int v);  // launches with fewer workgroups than this stay on conv_mfma_hx2p_kernel (0: never used)
 void conv_hx2q_set_target(int v);  // workgroups a launch is cut into when it has the tiles (two per CU)
 void conv_hx2q_set_tpw(int v);     // tools/kbench: force the tiles per workgroup

@@ -1,5 +1,5 @@
 // Single-layer benchmark of the conv kernels (development tool; not part of the library).
-//   conv_bench <S> <Cin> <Cout> [mode 0|1|2] [res 0|1|2] [B] [which: bx3|f32|hx2|hx2p|hx2q|hx2s]
+//   conv_bench <S> <Cin> <Cout> [mode 0|1|2] [res 0|1|2] [B] [which: bx3|f32|hx2|hx2p|hx2q|hx2s|hx2c]
 //   (mode 1: the stride-2 conv of a Downsample -- S is the OUTPUT size, the input is raw: hx2 or hx2s)
 // Every run also checks the selected kernel against the exact-fp32 MFMA kernel on the same data.
 // Builds one ConvArgs with random NHWC input / packed weights, launches it 20x, prints us and
@@ -17,6 +17,7 @@
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2p.hip"
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2q.hip"
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2s.hip"
+#include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2c.hip"
 #include "../../ratio_guided_multimodal_fm_amd/csrc/unet_kernels.hip"
 
 using namespace rgfm;
@@ -60,6 +61,7 @@ int main(int argc, char** argv) {
   const bool hx2p = argc > 7 && strcmp(argv[7], "hx2p") == 0;
   const bool hx2q = argc > 7 && strcmp(argv[7], "hx2q") == 0;
   const bool hx2s = argc > 7 && strcmp(argv[7], "hx2s") == 0;
+  const bool hx2c = argc > 7 && strcmp(argv[7], "hx2c") == 0;
   const int Sin = mode == CONV_UP2 ? S / 2 : (mode == CONV_S2 ? 2 * S : S);
   const int nt = Cout % 64 == 0 ? 2 : 1;
   CK(hipSetDevice(0));
@@ -69,6 +71,8 @@ int main(int argc, char** argv) {
   conv_hx2p_init();
   conv_hx2q_init();
   conv_hx2s_init();
+  conv_hx2c_init();
+  conv_hx2c_set_all(1);
   if (getenv("RGFM_HX2Q_MIN")) conv_hx2q_set_min(atoi(getenv("RGFM_HX2Q_MIN")));
   if (getenv("RGFM_HX2Q_TPW")) conv_hx2q_set_tpw(atoi(getenv("RGFM_HX2Q_TPW")));
   conv_hx2q_set_all(1);
@@ -174,12 +178,14 @@ int main(int argc, char** argv) {
   if (hx2p && !conv_hx2p_supported(ap, mode)) { printf("hx2p: unsupported shape\n"); return 1; }
   if (hx2q && !conv_hx2q_supported(ap, mode)) { printf("hx2q: unsupported shape\n"); return 1; }
   if (hx2s && !conv_hx2s_supported(a, mode)) { printf("hx2s: unsupported shape\n"); return 1; }
+  if (hx2c && !conv_hx2c_supported(ap, mode)) { printf("hx2c: unsupported shape\n"); return 1; }
   auto launch = [&]() {
     if (f32) launch_conv_mfma(a, mode, 0);
     else if (hx2) launch_conv_hx2(a, mode, 0);
     else if (hx2p) launch_conv_hx2p(ap, mode, 0);
     else if (hx2q) launch_conv_hx2q(ap, mode, 0);
     else if (hx2s) launch_conv_hx2s(a, 0);
+    else if (hx2c) launch_conv_hx2c(ap, 0);
     else launch_conv_bx3(a, mode, 0);
   };
   {  // reference: the exact-fp32 MFMA kernel on the same data
@@ -239,7 +245,7 @@ int main(int argc, char** argv) {
   float ms;
   hipEventElapsedTime(&ms, e0, e1);
   const double us = ms * 1e3 / reps;
-  printf("%s S=%d Cin=%d Cout=%d mode=%d res=%d B=%d: %8.1f us  %6.1f TFLOP/s (fp32-equivalent)\n", f32 ? "f32" : (hx2 ? "hx2" : (hx2p ? "hx2p" : (hx2q ? "hx2q" : (hx2s ? "hx2s" : "bx3")))), S, Cin,
+  printf("%s S=%d Cin=%d Cout=%d mode=%d res=%d B=%d: %8.1f us  %6.1f TFLOP/s (fp32-equivalent)\n", f32 ? "f32" : (hx2 ? "hx2" : (hx2p ? "hx2p" : (hx2q ? "hx2q" : (hx2s ? "hx2s" : (hx2c ? "hx2c" : "bx3"))))), S, Cin,
          Cout, mode, res, B, us, flops / us / 1e6);
 #ifdef RGFM_HX2Q_PROF
   if (hx2q) {
