@@ -121,6 +121,10 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, (RGFM_HX2P_QEXP
   const int l31p = lane & 31, hp_ = lane >> 5;
   const TileGeom g = a.g;
   const int W = g.W, H = g.H, HW = g.HW;
+  // rotation key of a halo record's four 16-byte slots: its halo column >> swz.  >> 2 keeps the fragment reads of 32- and
+  // 64-wide rasters free of bank conflicts but leaves those of 16- / 8- / 7-wide ones two- to three-way conflicted (a
+  // ds_read_b128 phase of 16 lanes then covers two or three raster rows); >> 1 is conflict-free there (tools/lds_swizzle.py)
+  const int swz = (W == 16 || W <= 8) ? 1 : 2;
 
   // tile origins of the block's one or two pixel tiles (block-uniform: scalar registers)
   auto tile_origin = [&](int tile, int& b0, int& row0) {
@@ -168,12 +172,12 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, (RGFM_HX2P_QEXP
     const int r = (int)(__umul24((unsigned)q, mW) >> 16), x = q - r * W;
     arec[mt] = ga_w * a.halo_px + (s * HR + r) * WR + x;
     // byte offset of this lane's fragment of tap (ky = 0, kx) inside a halo buffer, plane h / l: in THIS kernel the
-    // four 16-byte slots of a halo record are swizzled with its halo column, (x >> 2) & 3 -- 16 consecutive
+    // four 16-byte slots of a halo record are swizzled with its halo column, (x >> swz) & 3 -- 16 consecutive
     // columns still cover all 16 slot columns of the bank row, and the term no longer depends on the kernel row,
     // so the six offsets are computed once per block instead of per tap
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-      const int sw = ((x + kx) >> 2) & 3;
+      const int sw = ((x + kx) >> swz) & 3;
       aofs[mt][kx][0] = (arec[mt] + kx) * HRW + ((hp_ ^ sw) & 3) * 16;
       aofs[mt][kx][1] = (arec[mt] + kx) * HRW + (((2 + hp_) ^ sw) & 3) * 16;
     }
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, (RGFM_HX2P_QEXP
         }
         ok = ok && (b < a.B);
         const int rec = ga * a.halo_px + hp;
-        adst[j] = (int)__umul24((unsigned)rec, HRW) + ((((q4 >> 1) ^ (hx >> 2)) & 3) * 16) + (q4 & 1) * 8;  // plane l: ^ 32
+        adst[j] = (int)__umul24((unsigned)rec, HRW) + ((((q4 >> 1) ^ (hx >> swz)) & 3) * 16) + (q4 & 1) * 8;  // plane l: ^ 32
         if (ok) {
           poff[j] = (int)__umul24(__umul24((unsigned)b, (unsigned)a.Hin) + (unsigned)y, (unsigned)a.Win) + x;  // < 2^24 pixels
           okmask |= 1u << j;
