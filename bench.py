@@ -28,6 +28,9 @@ Rank 0 prints ONE JSON line with the driver's contract fields plus
                  against a float4 copy measured in this process.
   cpu_baseline : the CPU oracle (a C port of the reference algorithm, test
                  infrastructure) timed on this host's cores on a bounded sample (N=1 only).
+  parity_check : BASELINE.md section 4's gate on the number itself: eight rows of the LAST timed call are followed by
+                 the CPU oracle over all Euler steps from that call's own (x0, y0) and the MC set it produced;
+                 max |difference| must be within 1e-4 or the run fails (rank 0, after the timed region).
 """
 import argparse
 import json
@@ -70,6 +73,8 @@ def parse():
                    help="skip the hipEvent kernel-class timers (use under rocprofv3)")
     p.add_argument("--no-alt-mode", action="store_true",
                    help="skip the extra call in exact-fp32-MFMA mode (reported beside the default mode)")
+    p.add_argument("--no-parity-check", action="store_true",
+                   help="skip the oracle check of the last timed call's rows (use under rocprofv3)")
     p.add_argument("--no-arith-check", action="store_true",
                    help="skip the small float64 error check after the timed region (use under rocprofv3: the trace "
                         "then ends with the guided main loop)")
@@ -105,12 +110,33 @@ def cpu_baseline(fm, fs, rr, euler_steps, B_full, N_full):
     }
 
 
+PARITY_TOL = 1e-4  # BASELINE.md section 4 / SURVEY 8c: max |difference| of a full sampler call on outputs in [-6, 6]
+
+
+def parity_check(fm, fs, x0, y0, kept, out, euler_steps, gamma, nrows=8):
+    """Rows of the timed call against the CPU oracle: same (x0, y0), the MC set THAT call produced, every Euler step."""
+    import numpy as np
+    from oracle import oracle as O
+    B = x0.shape[0]
+    rows = sorted(set(int(round(i * (B - 1) / max(nrows - 1, 1))) for i in range(nrows)))
+    t0 = time.perf_counter()
+    ox, oy = O.sample_pair(O.desc_of(fm), O.blob_of(fm), O.desc_of(fs), O.blob_of(fs), x0[rows].cpu().numpy(),
+                           y0[rows].cpu().numpy(), kept["mc_x1"].cpu().numpy(), kept["mc_y1"].cpu().numpy(),
+                           kept["mc_ratios"].cpu().numpy(), euler_steps, gamma, 0, euler_steps)
+    dx = float(np.abs(out[0][rows].cpu().numpy() - ox).max())
+    dy = float(np.abs(out[1][rows].cpu().numpy() - oy).max())
+    return {"rows": len(rows), "row_indices": rows, "max_abs": max(dx, dy), "max_abs_x": dx, "max_abs_y": dy,
+            "tolerance": PARITY_TOL, "steps": euler_steps,
+            "what": "rows of the LAST timed call (its x0, y0 and the MC set it produced) followed by the CPU oracle over "
+                    "all Euler steps", "oracle_seconds": time.perf_counter() - t0}
+
+
 def kernel_sources_sha():
     """sha256 over the conv kernel sources: ties a committed PMC traffic file to the code it was measured on."""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "ratio_guided_multimodal_fm_amd", "csrc")
-    for name in ("conv_hx2_common.h", "conv_mfma_hx2.hip", "conv_mfma_hx2p.hip", "conv_mfma_hx2q.hip", "conv_mfma_hx2s.hip", "conv_mfma_hx2c.hip", "conv_mfma_bx3.hip",
+    for name in ("conv_hx2_common.h", "conv_mfma_hx2.hip", "conv_mfma_hx2p.hip", "conv_mfma_hx2q.hip", "conv_mfma_hx2s.hip", "conv_mfma_hx2c.hip", "conv_mfma_hx2d.hip", "conv_mfma_bx3.hip",
                  "conv_mfma.hip", "rgfm_device.h", "rgfm_kernels.h"):
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(f.read())
@@ -127,7 +153,10 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # under a torch.distributed.run launch (RANK in the environment) the RCCL group is made at ANY world size, so a
+    # one-rank launch walks the same barrier / gather / all_reduce code as the driver's N > 1 runs
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -150,13 +179,15 @@ def main():
     resident = [tuple(t.to(dev) for t in (x0, y0, mx0, my0)) for _ in range(calls)]
     torch.cuda.synchronize()
 
+    kept = {}  # references to the MC set of the latest call (no copies, no synchronisation): the parity gate reads them
+
     def one_call(i):
         return sharded_paired_sampler(fm, fs, rr, "mc_feng", args.gamma, args.euler_steps, resident[i], dev,
-                                      gather="rank0")
+                                      gather="rank0", keep=kept)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -188,7 +219,7 @@ def main():
                 hbm_classes[name] = _engine.profile_read(k)
         _engine.profile(enable=False)
     ranks = None
-    if world > 1:
+    if use_dist:
         # what every rank saw, gathered over RCCL: its rank, the world size of ITS process group, its device ordinal and its
         # own time for the K calls -- the line then proves that N ranks on N devices ran
         mine = torch.tensor([float(rank), float(dist.get_world_size()), float(torch.cuda.current_device()), elapsed],
@@ -200,6 +231,11 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    parity = None
+    if rank == 0 and not args.no_parity_check:
+        # the number is reported only with the outputs of the timed run inside the tolerance
+        parity = parity_check(fm, fs, resident[calls - 1][0], resident[calls - 1][1], dict(kept), out, args.euler_steps,
+                              args.gamma)
     conv_mode_env = os.environ.get("RGFM_CONV")
     conv_mode = conv_mode_env or "hx2"
     alt = None
@@ -384,8 +420,13 @@ def main():
             line["ranks"] = ranks
         if cpu is not None:
             line["cpu_baseline"] = cpu
+        if parity is not None:
+            line["parity_check"] = parity
         print(json.dumps(line), flush=True)
-    if world > 1:
+        if parity is not None and not parity["max_abs"] <= PARITY_TOL:
+            raise SystemExit(f"parity gate failed: max |difference| {parity['max_abs']:.3e} > {PARITY_TOL:g} on rows "
+                             f"{parity['row_indices']} of the timed call")
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -46,17 +46,8 @@ __device__ __forceinline__ float silu_scaled(float zs) {
   return zs * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
-// Low side of the raw staging path: S_A a is held as fp16(S_A a) + fp16(remainder); the remainder plane is an fp16
-// subnormal below |S_A a| = 2^-3, so the pair keeps 22 significant bits only above that and has an ABSOLUTE error floor
-// of 2^-25 / S_A below.  A producer's wave block whose largest |value| is under HX_SMALL = 2^-8 (S_A a < 2^-4: every
-// element already loses bits) raises flag bit 1; anything larger keeps the error of every element below
-// 2^-25 / (S_A HX_SMALL) = 2^-21 of the block's maximum.
-constexpr float HX_SMALL = 0.00390625f;
-__device__ __forceinline__ void hx_small_flag(unsigned* flag, float m) {  // m: this lane's max |output|; wave-uniform call
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if (m > 0.f && m < HX_SMALL && (threadIdx.x & 63) == 0) atomicOr(flag, 2u);
-}
+// (HX_SMALL / hx_small_flag, the low side of the raw staging path, live in rgfm_device.h: the bf16x3 and fp32 kernels
+// check it too when they produce a tensor that a two-plane conv stages raw)
 
 constexpr int HRW = 64;  // bytes per LDS record: [plane h | plane l] x 16 fp16
 // byte offset of 16-byte slot (plane, half) inside record `rec`

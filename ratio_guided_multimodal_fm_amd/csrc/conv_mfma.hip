@@ -192,6 +192,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         if (valid) a.out[pix * a.Cout + c] = v;
       }
     }
+  if (a.small_check && a.range_flag) {  // (ConvArgs::small_check: see conv_mfma_bx3.hip; wave-uniform)
+    float m = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (vmask[mt] & (1u << r)) m = fmaxf(m, fabsf(acc[mt][nt][r]));
+    hx_small_flag(a.range_flag, m);
+  }
 
   if (a.stats_out) {
     int nw;
@@ -525,6 +536,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_pf_kernel(const ConvArgs a) 
         if (valid) a.out[pix * a.Cout + c] = v;
       }
     }
+  if (a.small_check && a.range_flag) {  // (ConvArgs::small_check: see conv_mfma_bx3.hip; wave-uniform)
+    float m = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (vmask[mt] & (1u << r)) m = fmaxf(m, fabsf(acc[mt][nt][r]));
+    hx_small_flag(a.range_flag, m);
+  }
   if (a.stats_out) {
     int nw;
     if (g.spt == 1) {

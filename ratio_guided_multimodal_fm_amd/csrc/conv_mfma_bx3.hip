@@ -493,6 +493,20 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_bx3w_kernel(const ConvArgs a
           for (int nt = 0; nt < NT; ++nt) op[nt * 32] = acc[mt][nt][r];
         }
       }
+    // ConvArgs::small_check (set in two-plane mode only): this conv was routed here at create (weights or norm parameters
+    // outside the fp16 window) but its output is still staged RAW by a two-plane conv downstream -- the low side of that
+    // representation is this producer's to check, whichever kernel it runs on
+    if (a.small_check && a.range_flag) {
+      float m = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (FULL || (vmask[mt] & (1u << r))) m = fmaxf(m, fabsf(acc[mt][nt][r]));
+      hx_small_flag(a.range_flag, m);
+    }
     if (a.stats_out) {
       int nw;
       if (FULL) {

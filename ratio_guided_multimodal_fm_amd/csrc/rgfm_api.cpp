@@ -345,8 +345,10 @@ void launch_conv(const ConvArgs& c, int mode, hipStream_t s) {
 // Every U-Net / FlowMatchingModel handle owns one device word.  conv_mfma_hx2*.hip OR into it: bit 0 when a staged
 // activation reaches |S_A a| >= 32768 (fp16 would overflow), bit 1 when an output that a later conv stages raw is too
 // small for the two-plane representation (ConvArgs::small_check).  Either way the results of the handle's calls since
-// the last reset are not fp32-class and the caller repeats them with the handle switched to RGFM_CONV_BX3 (fp32
-// range).  Per handle, so that two threads / two engines on one device cannot consume each other's flag.
+// the last reset are not fp32-class and the caller repeats them with the handle switched to RGFM_CONV_BX3 (bit 0: fp32's
+// exponent range at the top) or to RGFM_CONV_F32 (bit 1: the exact fp32 matrix-core convs, the reference's arithmetic
+// at any magnitude) -- what _engine._range_guarded and INTEGRATION.md section B do.  Per handle, so that two threads /
+// two engines on one device cannot consume each other's flag.
 static int read_flag_word(unsigned* word, int* flagged, int reset, hipStream_t s) {
   if (!flagged) return fail(RGFM_EINVAL, "null output");
   *flagged = 0;
@@ -529,6 +531,17 @@ void fill_hx2(ConvArgs& c, const unsigned short* packedh, const float* hq, unsig
   c.wpkh = packedh + w.w_hx2, c.hq = hq + 4 * w.hq, c.range_flag = flag;
   if (w.w_hx9) c.wpkh9 = packedh + (w.w_hx9 - 1);
   if (sk) c.wskiph = packedh + sk->w_hx2, c.hq_skip = hq + 4 * sk->hq;
+}
+
+// The normalised inputs of the fp16 path are S_A silu(gamma xhat + beta): in range for every trained net the reference
+// can produce, but a conv whose norm parameters are tiny (the activation would sit in the fp16 subnormals) or huge is
+// routed to the split-bf16 kernel once, at create, like a conv with out-of-window weights.  `host` = the parameter blob.
+bool norm_params_ok(const std::vector<float>& host, size_t gw, size_t gb, int C) {
+  float mg = 0.f, mb = 0.f;
+  for (int i = 0; i < C; ++i) mg = std::max(mg, std::fabs(host[gw + i])), mb = std::max(mb, std::fabs(host[gb + i]));
+  if (!(mg <= 3.0e38f) || !(mb <= 3.0e38f)) return false;
+  const float hi = 8.f * mg + mb, lo = std::max(mg, mb);  // |gamma xhat + beta| for |xhat| <= 8; the activation's scale
+  return hi < 1024.f && lo >= 0.015625f;
 }
 
 double conv_flops(int B, int HW, int cout, int kprod) { return 2.0 * B * HW * (double)cout * kprod; }
@@ -820,20 +833,12 @@ extern "C" int rgfm_unet_create(const rgfm_unet_desc* desc, const float* params_
   for (ConvW& w : h->up) pack_one(h, w, CONV_S1, s), all.push_back(&w);
   if (read_hx_flags(h->hq, h->n_hq, all, s) != RGFM_OK) return bail(RGFM_EHIP, "reading the fp16 scale records failed");
   {
-    // The normalised inputs of the fp16 path are S_A silu(gamma xhat + beta): in range for every trained net the
-    // reference can produce, but a conv whose norm parameters are tiny (the activation would sit in the fp16
-    // subnormals) or huge is routed to the split-bf16 kernel here, once, like a conv with out-of-window weights.
+    // (norm_params_ok: convs behind a GroupNorm with out-of-window parameters leave the fp16 path here)
     std::vector<float> host(n_floats);
     if (hipMemcpyAsync(host.data(), h->params, n_floats * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess)
       return bail(RGFM_EHIP, "reading the parameters back failed");
-    auto norm_ok = [&](size_t gw, size_t gb, int C) {
-      float mg = 0.f, mb = 0.f;
-      for (int i = 0; i < C; ++i) mg = std::max(mg, std::fabs(host[gw + i])), mb = std::max(mb, std::fabs(host[gb + i]));
-      if (!(mg <= 3.0e38f) || !(mb <= 3.0e38f)) return false;
-      const float hi = 8.f * mg + mb, lo = std::max(mg, mb);  // |gamma xhat + beta| for |xhat| <= 8; the activation's scale
-      return hi < 1024.f && lo >= 0.015625f;
-    };
+    auto norm_ok = [&](size_t gw, size_t gb, int C) { return norm_params_ok(host, gw, gb, C); };
     for (auto* v : {&h->enc, &h->mid, &h->dec})
       for (ResW& r : *v) {
         if (!norm_ok(r.n1w, r.n1b, r.cin)) r.c1.hx_ok = false;
@@ -1193,9 +1198,7 @@ int pair_loop(EvalX&& eval_x, EvalY&& eval_y, float* x_inout, float* y_inout, co
     DevState* ds;
     hipStream_t s, caller;
     hipGraphExec_t* exec;
-    bool armed = true;
     ~ExitGuard() {
-      if (!armed) return;
       if (*exec) (void)hipEventRecord(ds->graph_done, s);
       if (s != caller) {
         (void)hipEventRecord(ds->main_join, s);
@@ -1212,9 +1215,20 @@ int pair_loop(EvalX&& eval_x, EvalY&& eval_y, float* x_inout, float* y_inout, co
         HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
         const int rc = one_step(i, true);
         const hipError_t ce = hipStreamEndCapture(s, &graph);
-        if (rc) return rc;
-        if (ce != hipSuccess || !graph) return fail(RGFM_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
-        HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        if (rc) {  // (a captured graph that will never run: nothing refers to it)
+          if (graph) (void)hipGraphDestroy(graph);
+          return rc;
+        }
+        if (ce != hipSuccess || !graph) {
+          if (graph) (void)hipGraphDestroy(graph);
+          return fail(RGFM_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+        }
+        const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (ie != hipSuccess) {
+          exec = nullptr;
+          (void)hipGraphDestroy(graph);
+          return fail(RGFM_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
+        }
         ds->graphs.push_back({exec, graph});
       }
       HIP_TRY(hipGraphLaunch(exec, s));
@@ -1223,12 +1237,8 @@ int pair_loop(EvalX&& eval_x, EvalY&& eval_y, float* x_inout, float* y_inout, co
     const int rc = one_step(i, guided);
     if (rc) return rc;
   }
-  exit_guard.armed = false;
-  if (exec) HIP_TRY(hipEventRecord(ds->graph_done, s));
-  if (s != caller) {
-    HIP_TRY(hipEventRecord(ds->main_join, s));
-    HIP_TRY(hipStreamWaitEvent(caller, ds->main_join, 0));
-  }
+  // (the guard's destructor records graph_done and joins `main` into the caller's stream -- on this path too, so that a
+  // failing record cannot skip the join)
   HIP_TRY(hipGetLastError());
   return RGFM_OK;
 }
@@ -2160,6 +2170,9 @@ struct FmRun {
       // VelocityDecoder.forward (:100-124); fc1 rows re-indexed so the result is the NHWC 7x7x256 map
       launch_linear_mfma(comb, h->packed + h->f1w_pk, h->packed + h->f1b_pk, d0, B, F + T, FM_P * FM_CF, F + T,
                          FM_P * FM_CF, s);
+      // deconv1 stages this map RAW (no norm in front, flow_matching.py:113-116): the low side of the two-plane
+      // representation is checked here, as a producing conv's epilogue would (ConvArgs::small_check)
+      if (g_modes.conv == CONV_ARITH_HX2 && h->d1.hx_ok) launch_range_low_check(d0, B, FM_P, FM_CF, h->range_flag, s);
     }
     Map m0;
     m0.data = d0, m0.C = FM_CF, m0.S = 7;
@@ -2235,6 +2248,16 @@ extern "C" int rgfm_fmnet_create(const rgfm_fmnet_desc* desc, const float* param
     packh(h->d1, CONV_T2), packh(h->d2, CONV_T2);
     std::vector<ConvW*> all{&h->ec[0], &h->ec[1], &h->ec[2], &h->c3, &h->d1, &h->d2};
     if (read_hx_flags(h->hq, h->n_hq, all, s) != RGFM_OK) return bail(RGFM_EHIP, "reading the fp16 scale records failed");
+    // (as rgfm_unet_create: a conv behind a GroupNorm with out-of-window parameters leaves the fp16 path)
+    std::vector<float> host(n_floats);
+    if (hipMemcpyAsync(host.data(), h->params, n_floats * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+      return bail(RGFM_EHIP, "reading the parameters back failed");
+    const int ech[3] = {32, 64, 128};
+    for (int i = 0; i < 3; ++i)
+      if (!norm_params_ok(host, h->egw[i], h->egb[i], ech[i])) h->ec[i].hx_ok = false;
+    if (!norm_params_ok(host, h->dgw[0], h->dgb[0], 128)) h->d2.hx_ok = false;
+    if (!norm_params_ok(host, h->dgw[1], h->dgb[1], 64)) h->c3.hx_ok = false;
   }
   for (int i = 0; i < 3; ++i) {  // encoder conv2 / conv3 are stride 2 (phase-ordered weights), conv4 stride 1
     const ConvW& w = h->ec[i];

@@ -112,6 +112,18 @@ __device__ __forceinline__ void fin_arrive(const ConvArgs& a, int b, int lane, i
   }
 }
 
+// Low side of the raw staging path: S_A a is held as fp16(S_A a) + fp16(remainder); the remainder plane is an fp16
+// subnormal below |S_A a| = 2^-3, so the pair keeps 22 significant bits only above that and has an ABSOLUTE error floor
+// of 2^-25 / S_A below.  A producer's wave block whose largest |value| is under HX_SMALL = 2^-8 (S_A a < 2^-4: every
+// element already loses bits) raises flag bit 1; anything larger keeps the error of every element below
+// 2^-25 / (S_A HX_SMALL) = 2^-21 of the block's maximum.
+constexpr float HX_SMALL = 0.00390625f;
+__device__ __forceinline__ void hx_small_flag(unsigned* flag, float m) {  // m: this lane's max |output|; wave-uniform call
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (m > 0.f && m < HX_SMALL && (threadIdx.x & 63) == 0) atomicOr(flag, 2u);
+}
+
 // Stage the input halo tile of channel chunk `c` (16 channels starting at concat
 // channel c) into sA[halo_px][LDP].  Shared with conv_out.
 template <int MODE>

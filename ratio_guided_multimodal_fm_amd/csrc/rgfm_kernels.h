@@ -87,6 +87,11 @@ struct ConvArgs {
   const float* gn_beta;
   int gn_nparts0;          // parts of in0: gn_g.nparts, or 4 x that when in0 was written by a CONV_T2 launch
   TileGeom gn_g;           // tiling of the raster the parts refer to (part sizes)
+  // conv_mfma_hx2d.hip: the input ALREADY normalised, activated and split ("P format": [pixel][C0/16][h ch 0-7 | h ch
+  // 8-15 | l ch 0-7 | l ch 8-15] fp16, 64 B per (pixel, 16-channel chunk), written by the producing conv's epilogue or
+  // by launch_hx_presplit) -- staged by LDS-DMA only; `zeros` = 64 zero bytes on the device (the padding records' source)
+  const void* pin0;
+  const void* zeros;
   const float* wpk;  // packed 3x3 weights  [Cout/(32NT)][Cin/16][9][32NT][16]
   const void* wpk3;  // the same weights as three bf16 planes [..][9][32NT][3][16] (conv_mfma_bx3.hip) or null
   const void* wskip3;
@@ -221,7 +226,6 @@ void launch_conv_hx2(const ConvArgs& a, int mode, hipStream_t s);
 bool conv_hx2p_supported(const ConvArgs& a, int mode);
 int conv_hx2p_init();
 void conv_hx2p_set_half(int v);  // launches with fewer workgroups than this are cut finer (0: never; the CU count)
-void conv_hx2p_set_chunk(int v);  // 0: no chunk-sized units for the under-filled 64-channel cut (A/B)
 void conv_hx2p_set_w4(int v);  // tools/kbench A/B: 1 / 2 = four-wave workgroups forced, see conv_mfma_hx2p.hip
 void launch_conv_hx2p(const ConvArgs& a, int mode, hipStream_t s);
 // four-waves-per-SIMD version (conv_mfma_hx2q.hip: one tile x 64 channels at a time, two workgroups per CU, several
@@ -240,6 +244,13 @@ int conv_hx2c_init();
 void conv_hx2c_set(int on);
 void conv_hx2c_set_all(int on);
 void launch_conv_hx2c(const ConvArgs& a, hipStream_t s);
+// conv_mfma_hx2d.hip: stride-1 convs of the 16x16 / 8x8 levels over a P-format input (ConvArgs::pin0), staged by LDS-DMA only
+bool conv_hx2d_supported(const ConvArgs& a, int mode);
+int conv_hx2d_init();
+void conv_hx2d_set(int on);
+void launch_conv_hx2d(const ConvArgs& a, hipStream_t s);
+// P format of silu(scale x + shift) from an fp32 NHWC map and per-(sample, channel) pairs ab[B][C][2]
+void launch_hx_presplit(const float* in, const float* ab, void* pout, int B, int HW, int C, hipStream_t s);
 void conv_hx2q_set_min(int v);  // launches with fewer workgroups than this stay on conv_mfma_hx2p_kernel (0: never used)
 void conv_hx2q_set_target(int v);  // workgroups a launch is cut into when it has the tiles (two per CU)
 void conv_hx2q_set_tpw(int v);     // tools/kbench: force the tiles per workgroup
@@ -266,6 +277,8 @@ void launch_permute_rows(const float* w, const float* b, float* wout, float* bou
 void launch_fm_time_embed(const float* t_dev, int t_count, int num_steps, int step, const float* freqs, float* out,
                           int B, int dim, int stride, int col0, hipStream_t s);
 void launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, hipStream_t s);
+// ORs 2 into *flag when a (sample, 32-channel) block of the NHWC map is non-zero but below HX_SMALL (see ConvArgs::small_check)
+void launch_range_low_check(const float* in, int B, int HW, int C, unsigned* flag, hipStream_t s);
 
 // ---- ratio-estimator helpers
 void launch_pool2(const float* in, const float* ab, float* out, int B, int H, int W, int C, hipStream_t s);

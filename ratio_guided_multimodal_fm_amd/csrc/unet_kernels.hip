@@ -544,6 +544,26 @@ void launch_fm_time_embed(const float* t_dev, int t_count, int num_steps, int st
                      freqs, out, B, dim, stride, col0);
 }
 
+// ------------------------------------------------------------------ low side of a raw-staged map (ConvArgs::small_check)
+// For a tensor that a two-plane fp16 conv stages RAW but that no conv produced (FlowMatchingModel: the fc1 output that
+// deconv1 consumes, flow_matching.py:113-116): one wave per (sample, 32-channel block) takes the largest |value| over the
+// sample's pixels and raises flag bit 1 exactly as a producing conv's epilogue would (hx_small_flag).
+__global__ __launch_bounds__(256) void range_low_check_kernel(const float* in, int B, int HW, int C, unsigned* flag) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const int nblk = C >> 5;
+  if (wave >= B * nblk) return;  // (wave-uniform)
+  const int b = wave / nblk, cb = wave - b * nblk;
+  const float* p = in + (size_t)b * HW * C + cb * 32 + (lane & 31);
+  float m = 0.f;
+  for (int px = lane >> 5; px < HW; px += 2) m = fmaxf(m, fabsf(p[(size_t)px * C]));
+  hx_small_flag(flag, m);
+}
+
+void launch_range_low_check(const float* in, int B, int HW, int C, unsigned* flag, hipStream_t s) {
+  const int waves = B * (C / 32);
+  hipLaunchKernelGGL(range_low_check_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, in, B, HW, C, flag);
+}
+
 // ------------------------------------------------------------------ layout helper (parity hook)
 __global__ void nhwc_to_nchw_kernel(const float* in, float* out, int B, int C, int HW) {
   const size_t total = (size_t)B * C * HW;

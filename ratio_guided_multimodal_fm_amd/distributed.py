@@ -86,13 +86,15 @@ def _all_gather_rows(t, counts, group):
 
 
 def sharded_paired_sampler(fm_x, fm_y, ratio_estimator, guidance_method, guidance_strength, num_steps,
-                           noise, device, backend=None, group=None, gather="rank0"):
+                           noise, device, backend=None, group=None, gather="rank0", keep=None):
     """Sharded equivalent of ``paired_sampler`` on explicit host noise.
 
     noise = (x0, y0, mc_x0, mc_y0): the FULL tensors, identical on every rank
     (every rank regenerates them from the seed; each slices its own rows).
     Returns (x, y) with all rows: on every rank for gather="all", on rank 0
     only (None, None elsewhere) for gather="rank0".
+    keep: optional dict that receives references to the gathered MC set the guided loop ran on
+    (``mc_x1``, ``mc_y1``, ``mc_ratios``) -- bench.py's parity gate follows rows of the timed call from it.
     """
     backend = backend or HipBackend()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -129,6 +131,8 @@ def sharded_paired_sampler(fm_x, fm_y, ratio_estimator, guidance_method, guidanc
         mc_x1 = _all_gather_rows(sx, counts, group)
         mc_y1 = _all_gather_rows(sy, counts, group)
         mc_r = _all_gather_rows(sr, counts, group)
+        if keep is not None:
+            keep.update(mc_x1=mc_x1, mc_y1=mc_y1, mc_ratios=mc_r)
 
     lo, hi = shard_bounds(B, world, rank)
     x = x0[lo:hi].to(device, copy=True).contiguous()

@@ -164,6 +164,32 @@ def test_config2_own_gamma_all_steps(dev):
     assert maxdiff(ya[rows].cpu().numpy(), oy) < TOL_SAMPLER
 
 
+def test_config4_rank_shape_200_steps_strong_guidance(dev):
+    """BASELINE configs[4] as one rank sees it at 8 GPUs: 1024 rows, N_mc 256, ALL 200 Euler steps
+    (reference sweep: evaluate_mnist_svhn.py:130-165), for the two extrapolating guidance strengths gamma = 2 and 5
+    (gamma is not clamped, sample_mnist_svhn.py:170); rows from both ends and the middle are followed by the CPU
+    oracle over the whole trajectory from the same MC set."""
+    fm, fs, rr = make_module("mnist32", dev), make_module("svhn", dev), make_module("ratio_ms", dev)
+    B, N, S = 1024, 256, 200
+    noise = paired_noise(15, B, N, (1, 32, 32), (3, 32, 32))
+    mx1, my1 = noise[2].to(dev, copy=True), noise[3].to(dev, copy=True)
+    _engine.sample_two_streams(fm, mx1, fs, my1, S)
+    r = rr._engine.eval(mx1, my1, "ratio")
+    dx, bx = oracle_net("mnist32")
+    dy, by = oracle_net("svhn")
+    mxn, myn, rn = mx1.cpu().numpy(), my1.cpu().numpy(), r.cpu().numpy()
+    before = _engine.range_fallbacks
+    for gamma, rows in ((2.0, [0, 1, 511, 512, 1022, 1023]), (5.0, [2, 300, 513, 700, 1000, 1021])):
+        xa, ya = noise[0].to(dev, copy=True), noise[1].to(dev, copy=True)
+        _engine.sample_pair(fm, fs, xa, ya, mx1, my1, r, S, gamma)
+        assert torch.isfinite(xa).all() and torch.isfinite(ya).all()
+        ox, oy = O.sample_pair(dx, bx, dy, by, noise[0][rows].numpy(), noise[1][rows].numpy(), mxn, myn, rn, S, gamma, 0, S)
+        dxm, dym = maxdiff(xa[rows].cpu().numpy(), ox), maxdiff(ya[rows].cpu().numpy(), oy)
+        print(f"gamma={gamma}: max|dx| {dxm:.2e} max|dy| {dym:.2e} (|x| {float(np.abs(ox).max()):.1f}, |y| {float(np.abs(oy).max()):.1f})")
+        assert dxm < TOL_SAMPLER and dym < TOL_SAMPLER, (gamma, dxm, dym)
+    assert _engine.range_fallbacks == before
+
+
 def test_time_embedding_table_against_reference_fixture(dev):
     """a7: the sinusoidal embedding (cos half first, unscaled t; unet_flexible.py:16-36) as the DEVICE evaluates it
     in front of the time MLPs (rgfm_unet_time_embedding), against the reference's timestep_embedding fixture, for
@@ -381,6 +407,69 @@ def test_cli_mains_from_checkpoint_files(dev, tmp_path, monkeypatch):
     want = evaluate_mnist_svhn.run_sweep(fm.to(dev), fs.to(dev), lambda: rr.to(dev), cm.to(dev), cs.to(dev),
                                          ["none", "mc_feng"], [0.0, 1.0], 4, 3, dev, 5)
     assert res == want
+
+
+def test_cli_mains_sharded_at_world_one(dev, tmp_path, monkeypatch):
+    """The `--sharded` launch path of both CLIs (torch.distributed.run environment, init_from_env("nccl"),
+    make_sharded_sampler) on the GPU at world size 1: the sharded sampler draws the noise from the CPU generator in the
+    reference's order, so the files must equal the explicit-noise API under the same seed bit for bit."""
+    import ratio_guided_multimodal_fm_amd as R
+    from ratio_guided_multimodal_fm_amd import evaluate_mnist_svhn, sample_mnist_svhn
+    from ratio_guided_multimodal_fm_amd.distributed import make_sharded_sampler
+    from ratio_guided_multimodal_fm_amd.utils.flow_utils import paired_sampler
+    fm, fs, rr, cm, cs = _write_checkpoints(tmp_path)
+    monkeypatch.chdir(tmp_path)
+    for k, v in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29576")):
+        monkeypatch.setenv(k, v)
+    assert sample_mnist_svhn.main(["--guidance_method", "mc_feng", "--guidance_strength", "1.0", "--num_samples", "5",
+                                   "--num_steps", "4", "--mc_batch_size", "6", "--seed", "11", "--sharded"]) == 0
+    saved = torch.load(tmp_path / "outputs" / "mnist_svhn" / "samples_mc_feng_gamma1.0.pt")
+    from ratio_guided_multimodal_fm_amd import models as M
+    # (the CLI builds its modules between the seeding and the sampling, as the reference's does: their parameter
+    # initialisation consumes the CPU generator the sharded sampler then draws the noise from)
+    R.utils.set_seed(11)
+    M.FlowMatchingUNetMNIST(img_size=32), M.FlowMatchingUNetSVHN(), M.RatioEstimatorMNISTSVHN(loss_type="disc")
+    noise = (torch.randn(5, 1, 32, 32), torch.randn(5, 3, 32, 32), torch.randn(6, 1, 32, 32), torch.randn(6, 3, 32, 32))
+    xs, ys = paired_sampler(fm.to(dev), fs.to(dev), rr.to(dev), "mc_feng", 1.0, 5, 4, dev, 6, (1, 32, 32), (3, 32, 32),
+                            noise=noise, verbose=False)
+    assert torch.equal(saved["mnist"], xs.cpu()) and torch.equal(saved["svhn"], ys.cpu())
+
+    assert evaluate_mnist_svhn.main(["--guidance_methods", "none", "mc_feng", "--guidance_strengths", "0.0", "2.0",
+                                     "--num_samples", "6", "--num_steps", "3", "--mc_batch_size", "5", "--seed", "6",
+                                     "--sharded"]) == 0
+    res = json.load(open(tmp_path / "outputs" / "mnist_svhn" / "evaluation_results.json"))
+    R.utils.set_seed(6)
+    M.MNISTClassifier32(), M.SVHNClassifier(), M.FlowMatchingUNetMNIST(img_size=32), M.FlowMatchingUNetSVHN()
+
+    def make_ratio():  # (as the CLI: a fresh module per request, its initialisation draws from the generator too)
+        r = M.RatioEstimatorMNISTSVHN(loss_type="disc").to(dev)
+        r.load_state_dict(rr.state_dict())
+        return r
+    want = evaluate_mnist_svhn.run_sweep(fm.to(dev), fs.to(dev), make_ratio, cm.to(dev), cs.to(dev),
+                                         ["none", "mc_feng"], [0.0, 2.0], 6, 3, dev, 5,
+                                         sampler=make_sharded_sampler((1, 32, 32), (3, 32, 32), gather="all"))
+    assert res == want and len(res) == 3
+
+
+def test_bench_under_the_distributed_launcher(dev):
+    """`bench.py --gpus 1` launched the way the driver launches N > 1 (python -m torch.distributed.run, one rank): the
+    RANK / LOCAL_RANK / WORLD_SIZE plumbing, a ONE-rank RCCL group (barrier, the per-rank all_gather, the MAX
+    all_reduce), the kernel timers and the parity gate of the timed call, at a size that takes seconds."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29578", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1",
+           "--warmup", "1", "--batch-per-gpu", "24", "--mc", "16", "--euler-steps", "6", "--no-cpu-baseline",
+           "--no-alt-mode", "--no-arith-check"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["steps"] == 1
+    assert line["ranks"] == [{"rank": 0, "world_size_seen": 1, "device": 0, "seconds": line["ranks"][0]["seconds"]}]
+    assert line["parity_check"]["rows"] == 8 and line["parity_check"]["max_abs"] <= line["parity_check"]["tolerance"] == 1e-4
 
 
 def test_cli_sample28_from_checkpoint_files(dev, tmp_path, monkeypatch):

@@ -14,10 +14,18 @@
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_bx3.hip"
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma.hip"
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2.hip"
+#ifdef RGFM_KB_SCAFFOLD
+// round 3's timing ablations, phase stamps and rejected cuts (-DRGFM_HX2P_ABL=n, -DRGFM_HX2P_PROF, -DRGFM_HX2P_CHUNK_EXP,
+// -DRGFM_HX2Q_ABL=n, -DRGFM_HX2Q_PROF, ...): frozen copies of the kernels as they were before round 4 took the scaffolding out
+#include "variants/conv_mfma_hx2p_r03_scaffold.hip"
+#include "variants/conv_mfma_hx2q_r03_scaffold.hip"
+#else
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2p.hip"
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2q.hip"
+#endif
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2s.hip"
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2c.hip"
+#include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2d.hip"
 #include "../../ratio_guided_multimodal_fm_amd/csrc/unet_kernels.hip"
 
 using namespace rgfm;
@@ -62,6 +70,7 @@ int main(int argc, char** argv) {
   const bool hx2q = argc > 7 && strcmp(argv[7], "hx2q") == 0;
   const bool hx2s = argc > 7 && strcmp(argv[7], "hx2s") == 0;
   const bool hx2c = argc > 7 && strcmp(argv[7], "hx2c") == 0;
+  const bool hx2d = argc > 7 && strcmp(argv[7], "hx2d") == 0;
   const int Sin = mode == CONV_UP2 ? S / 2 : (mode == CONV_S2 ? 2 * S : S);
   const int nt = Cout % 64 == 0 ? 2 : 1;
   CK(hipSetDevice(0));
@@ -72,6 +81,7 @@ int main(int argc, char** argv) {
   conv_hx2q_init();
   conv_hx2s_init();
   conv_hx2c_init();
+  conv_hx2d_init();
   conv_hx2c_set_all(1);
   if (getenv("RGFM_HX2Q_MIN")) conv_hx2q_set_min(atoi(getenv("RGFM_HX2Q_MIN")));
   if (getenv("RGFM_HX2Q_TPW")) conv_hx2q_set_tpw(atoi(getenv("RGFM_HX2Q_TPW")));
@@ -79,9 +89,11 @@ int main(int argc, char** argv) {
   if (getenv("RGFM_HX2Q_CUT")) conv_hx2q_set_cut(atoi(getenv("RGFM_HX2Q_CUT")));
   if (getenv("RGFM_HX2P_W4")) conv_hx2p_set_w4(atoi(getenv("RGFM_HX2P_W4")));
   if (getenv("RGFM_HX2P_HALF")) conv_hx2p_set_half(atoi(getenv("RGFM_HX2P_HALF")));
+#ifdef RGFM_KB_SCAFFOLD
   if (getenv("RGFM_HX2P_CHUNK")) conv_hx2p_set_chunk(atoi(getenv("RGFM_HX2P_CHUNK")));
 #if RGFM_HX2P_QEXP
   if (getenv("RGFM_HX2P_Q")) conv_hx2p_set_q(atoi(getenv("RGFM_HX2P_Q")));
+#endif
 #endif
 
   ConvArgs a{};
@@ -175,6 +187,17 @@ int main(int argc, char** argv) {
   const double flops = 2.0 * B * S * S * (double)Cout * (9 * Cin + skipk);
   ConvArgs ap = a;  // the pipelined kernel takes the norm itself
   ap.ab = nullptr, ap.gn_stats0 = gstats, ap.gn_gamma = ggamma, ap.gn_beta = gbeta, ap.gn_nparts0 = gin.nparts, ap.gn_g = gin;
+  ConvArgs ad = a;  // conv_mfma_hx2d_kernel: the same input, normalised + activated + split beforehand (P format)
+  if (hx2d) {
+    void* pbuf;
+    hipMalloc(&pbuf, (size_t)B * Sin * Sin * Cin * 4);
+    launch_hx_presplit(a.in0, abbuf, pbuf, B, Sin * Sin, Cin, 0);
+    void* zer;
+    hipMalloc(&zer, 256);
+    hipMemset(zer, 0, 256);
+    ad.ab = nullptr, ad.pin0 = pbuf, ad.zeros = zer;
+    if (!conv_hx2d_supported(ad, mode)) { printf("hx2d: unsupported shape\n"); return 1; }
+  }
   if (hx2p && !conv_hx2p_supported(ap, mode)) { printf("hx2p: unsupported shape\n"); return 1; }
   if (hx2q && !conv_hx2q_supported(ap, mode)) { printf("hx2q: unsupported shape\n"); return 1; }
   if (hx2s && !conv_hx2s_supported(a, mode)) { printf("hx2s: unsupported shape\n"); return 1; }
@@ -186,6 +209,7 @@ int main(int argc, char** argv) {
     else if (hx2q) launch_conv_hx2q(ap, mode, 0);
     else if (hx2s) launch_conv_hx2s(a, 0);
     else if (hx2c) launch_conv_hx2c(ap, 0);
+    else if (hx2d) launch_conv_hx2d(ad, 0);
     else launch_conv_bx3(a, mode, 0);
   };
   {  // reference: the exact-fp32 MFMA kernel on the same data
@@ -245,7 +269,7 @@ int main(int argc, char** argv) {
   float ms;
   hipEventElapsedTime(&ms, e0, e1);
   const double us = ms * 1e3 / reps;
-  printf("%s S=%d Cin=%d Cout=%d mode=%d res=%d B=%d: %8.1f us  %6.1f TFLOP/s (fp32-equivalent)\n", f32 ? "f32" : (hx2 ? "hx2" : (hx2p ? "hx2p" : (hx2q ? "hx2q" : (hx2s ? "hx2s" : (hx2c ? "hx2c" : "bx3"))))), S, Cin,
+  printf("%s S=%d Cin=%d Cout=%d mode=%d res=%d B=%d: %8.1f us  %6.1f TFLOP/s (fp32-equivalent)\n", f32 ? "f32" : (hx2 ? "hx2" : (hx2p ? "hx2p" : (hx2q ? "hx2q" : (hx2s ? "hx2s" : (hx2c ? "hx2c" : (hx2d ? "hx2d" : "bx3")))))), S, Cin,
          Cout, mode, res, B, us, flops / us / 1e6);
 #ifdef RGFM_HX2Q_PROF
   if (hx2q) {

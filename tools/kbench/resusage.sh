@@ -5,4 +5,4 @@ cd "$(dirname "$0")"
   --cuda-device-only -c conv_bench.hip -o /dev/null -Rpass-analysis=kernel-resource-usage "$@" 2>&1 |
   awk '/Function Name:/ {n=$0; sub(/.*Function Name: /,"",n); sub(/ \[.*/,"",n)}
        / VGPRs:/ {v=$0; sub(/.*VGPRs: /,"",v); sub(/ \[.*/,"",v)}
-       /ScratchSize/ {s=$0; sub(/.*lane\]: /,"",s); sub(/ \[.*/,"",s); if (n ~ /conv_mfma_hx2[pqsc]?_kernel/) print n, "vgpr", v, "scratch", s}'
+       /ScratchSize/ {s=$0; sub(/.*lane\]: /,"",s); sub(/ \[.*/,"",s); if (n ~ /conv_mfma_hx2[pqscd]?_kernel/) print n, "vgpr", v, "scratch", s}'

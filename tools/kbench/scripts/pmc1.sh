@@ -11,7 +11,7 @@ for w in hx2p hx2q; do
              "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM SQ_INSTS_SALU" \
              "GRBM_GUI_ACTIVE SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES"; do
     i=$((i+1))
-    rm -rf /tmp/p_$w_$i
+    rm -rf /tmp/p_${w}_$i
     timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/p_${w}_$i -- $K $ARGS 512 $w > /dev/null 2>&1 || { echo "pass $w $i failed"; continue; }
     f=$(find /tmp/p_${w}_$i -name '*counter_collection.csv' | head -1)
     python3 - "$f" "$w" <<'PY'

@@ -1,3 +1,5 @@
+// FROZEN COPY (round 3, commit ef17e0f) of the kernel with its experiment scaffolding -- timing ablations (results wrong by
+// construction), phase stamps, rejected cuts.  tools/kbench only (-DRGFM_KB_SCAFFOLD); the shipped kernel is csrc/'s.
 // conv_mfma_hx2p.hip -- pipelined version of conv_mfma_hx2_kernel for the stride-1 and upsampling convs
 // (CONV_S1, CONV_UP2: 96 % of the conv time of a U-Net evaluation).  Same arithmetic (two scaled fp16 planes, three
 // f16-MFMA products per fp32 product), same tiling, prologue and epilogue; the K loop is re-cut so that the matrix
@@ -34,7 +36,33 @@
 #include "conv_hx2_common.h"
 
 namespace rgfm {
+void conv_hx2p_set_chunk(int v);
+void conv_hx2p_set_q(int v);
 
+#ifndef RGFM_HX2P_ABL
+#define RGFM_HX2P_ABL 0
+#endif
+#ifndef RGFM_HX2P_FAST
+#define RGFM_HX2P_FAST 1
+#endif
+#ifndef RGFM_HX2P_GNEARLY
+#define RGFM_HX2P_GNEARLY 0  // (1: request the first channel's partials at the top of the kernel -- measured: no gain, more live registers)
+#endif
+#ifndef RGFM_HX2P_TAIL
+#define RGFM_HX2P_TAIL 1
+#endif
+#ifndef RGFM_HX2P_PRIO
+#define RGFM_HX2P_PRIO 0
+#endif
+#ifdef RGFM_HX2P_PROF
+__device__ unsigned long long g_hx2p_prof[34];  // [wave][pro+fill, stage, mfma, barrier], [32] epilogue of wave 0, [33] blocks
+#define PPROF_T(var) const long long var = clock64()
+#define PPROF_ADD(slot, t0, t1) pacc[slot] += (t1) - (t0)
+__device__ long long g_hx2p_trace[2][64][9];  // block 3, waves 0 and 4: per unit {stage begin, stage end, mfma begin, mfma end, barrier begin, barrier end}
+#else
+#define PPROF_T(var)
+#define PPROF_ADD(slot, t0, t1)
+#endif
 
 // CFG: how a workgroup is cut.  HX2P_TWO_TILES: 8 waves = two 256-pixel tiles x one channel group (32 NT channels), the
 // weights are staged once for both tiles; HX2P_PAIRN: 8 waves = one tile x two channel groups (Cout % 128 == 0), the
@@ -44,15 +72,25 @@ namespace rgfm {
 // under-filled launches, where one tile per workgroup means twice the workgroups.
 // HX2P_PAIRN_HALF: as HX2P_PAIRN with 32-channel groups (NT = 1): one tile x 64 of a 128-channel weight block, twice the
 // workgroups -- for launches that would otherwise leave CUs without a workgroup (the 8x8 level, small batches).
-// (Chunk-sized units for that cut -- nine taps between two barriers -- were measured 2 ... 9 % slower on every under-filled
-// launch: a unit's time is proportional to the work in it, not to the number of barriers.  tools/kbench/variants/ has them.)
-enum { HX2P_TWO_TILES = 0, HX2P_PAIRN = 1, HX2P_FOUR_WAVES = 2, HX2P_PAIRN_HALF = 3 };
+// HX2P_PAIRN_HALF_C (round 3): HX2P_PAIRN_HALF with CHUNK-sized units -- all nine taps of a 16-channel chunk between two
+// barriers, the weight buffers hold a whole chunk (2 x 37 KB: there is room where this cut runs, one under-filled
+// workgroup per CU).  Such launches are one round of <= 256 workgroups whose time is the serial chain of a unit
+// (barrier, table read, transform, store, barrier) times the number of units: a third of the units, three times the
+// MFMAs behind each chain.  Same per-element summation order: bit-identical results.  MEASURED (tools/kbench
+// scripts/q12.sh, -DRGFM_HX2P_CHUNK_EXP): 2 ... 9 % SLOWER than the unit-sized form on every such launch (8x8 at B = 512 /
+// 256, 16x16 at B = 128 / 64) -- their time is proportional to the work in a unit, not to the number of barriers; built
+// for kbench only.
+enum { HX2P_TWO_TILES = 0, HX2P_PAIRN = 1, HX2P_FOUR_WAVES = 2, HX2P_PAIRN_HALF = 3, HX2P_PAIRN_HALF_C = 4 };
 
 template <int NT, int MODE, int CFG>
-__global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a, const int num_tiles) {
-  constexpr bool PAIRN = CFG == HX2P_PAIRN || CFG == HX2P_PAIRN_HALF;
-  constexpr bool HALF = CFG == HX2P_PAIRN_HALF;  // the packed weight blocks hold 128 channels, this workgroup takes 64 of them
-  constexpr int TPU = 3;                       // taps per unit
+#ifndef RGFM_HX2P_QEXP
+#define RGFM_HX2P_QEXP 0  // (kbench experiment: NT = 1 one-tile x 64-channel workgroups at four waves per SIMD, two workgroups per CU)
+#endif
+__global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, (RGFM_HX2P_QEXP && NT == 1 && CFG == HX2P_PAIRN) ? 4 : 2) void conv_mfma_hx2p_kernel(const ConvArgs a, const int num_tiles) {
+  constexpr bool CW = CFG == HX2P_PAIRN_HALF_C;  // chunk-sized units
+  constexpr bool PAIRN = CFG == HX2P_PAIRN || CFG == HX2P_PAIRN_HALF || CW;
+  constexpr bool HALF = CFG == HX2P_PAIRN_HALF || CW;  // the packed weight blocks hold 128 channels, this workgroup takes 64 of them
+  constexpr int TPU = CW ? 9 : 3;              // taps per unit
   constexpr int UPC = 9 / TPU;                 // units per main chunk
   static_assert(!HALF || NT == 1, "HX2P_PAIRN_HALF: 2 groups x 32 channels");
   constexpr bool W4 = CFG == HX2P_FOUR_WAVES;
@@ -68,6 +106,10 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
   constexpr int NB = (UB / 16 + NTHR - 1) / NTHR;    // 16-byte weight items per thread and unit
   constexpr int MAXIT = (NA * 448 * 4 + NTHR - 1) / NTHR;  // halo items (pixel, 4 channels) per thread and chunk
   extern __shared__ __attribute__((aligned(16))) char smemp[];
+#ifdef RGFM_HX2P_PROF
+  long long pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  PPROF_T(tk0);
   const int abytes = (NA * a.halo_px + 1) * HRW;  // one halo buffer (+ a pad record: the store target of lanes past the halo)
   char* const sB = smemp + 2 * abytes;         // two unit-sized weight buffers
   float* const sTab = reinterpret_cast<float*>(sB + 2 * UB);  // [NA * spt][cin][2] S_A x (scale, shift) + a zero row
@@ -196,6 +238,10 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
     gn_gv = a.gn_gamma[have ? c : 0], gn_bv = a.gn_beta[have ? c : 0];
     gn_npt = npt;
   };
+#if RGFM_HX2P_GNEARLY
+  if (a.gn_stats0 && gn_active) gn_fetch(0);
+#endif
+  PPROF_T(tkx);
   f32x16 acc[2][NT];
   // bias (+ skip bias + time embedding) and, for an identity residual, the RAW residual values go into the
   // accumulators here; they are scaled by q only after the pipeline fill (finish_acc below), so that the 64 residual
@@ -211,6 +257,10 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
       if (a.temb && sample_ok) v += a.temb[((size_t)(a.temb_per_row ? bw : 0) + (a.step_ptr ? (size_t)*a.step_ptr : 0)) * a.temb_stride + c];
       add0[nt] = v * qmain;  // the accumulators hold q x the true sums
     }
+    PPROF_T(tky);
+#ifdef RGFM_HX2P_PROF
+    if (blockIdx.x == 3 && seg == 0 && lane == 0) g_hx2p_trace[grp][63][5] = tkx - tk0, g_hx2p_trace[grp][63][6] = tky - tkx;
+#endif
     if (a.res_mode == 1) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
@@ -244,6 +294,7 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
     }
   };
 
+  PPROF_T(tka);
   // ---- per-item decode, once: source pixel offset, LDS destination, validity bit, scale/shift slot
   const int q4 = tid & 3;
   const int nA = a.halo_px * 4;
@@ -379,6 +430,7 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
     }
   };
 
+  PPROF_T(tkb);
   if (a.gn_stats0 && gn_active) {
     // ---- consumer-side GroupNorm: scale/shift of this block's sample(s) from the producers' partial statistics.
     // Up to all waves take part: the block's R = NA * spt table rows (one per sample slot) are split over the NW waves,
@@ -391,7 +443,7 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
     double n = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll 1
     for (int k = 0; k < gn_kmax; ++k) {
-      gn_fetch(k);
+      if (k > 0 || !RGFM_HX2P_GNEARLY) gn_fetch(k);
       if (k == 0) gam[0] = gn_gv, bet[0] = gn_bv;
       else if (k == 1) gam[1] = gn_gv, bet[1] = gn_bv;
       else if (k == 2) gam[2] = gn_gv, bet[2] = gn_bv;
@@ -458,7 +510,9 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
     const hx_u32x4 d = {(unsigned)pv, (unsigned)(pv >> 32), (unsigned)cs, 0u};
     *reinterpret_cast<hx_u32x4*>(sDesc + tid * 16) = d;
   }
+  PPROF_T(tkc);
   __syncthreads();  // the scale/shift table and the chunk descriptors are complete
+  PPROF_T(tkd);
   const bool gn_on = has_tab;
   // ---- pipeline fill: halo of chunk 0 and weights of unit 0 in LDS, raw halo of chunk 1 and weights of unit 1 in registers
   {
@@ -486,13 +540,30 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
   }
   finish_acc();
   __syncthreads();
+  PPROF_T(tk1);
+  PPROF_ADD(grp * 4 + 0, tk0, tk1);
+#ifdef RGFM_HX2P_PROF
+  if (blockIdx.x == 3 && seg == 0 && lane == 0) {
+    long long* tr = g_hx2p_trace[grp][63];
+    tr[0] = tka - tk0, tr[1] = tkb - tka, tr[2] = tkc - tkb, tr[3] = tkd - tkc, tr[4] = tk1 - tkd;
+  }
+#endif
 
   // one tap (kernel column KX of the row at byte offset `rowoff`): fragments of this wave's 2 pixel tiles x NT channel
   // tiles, 3 MFMAs per tile pair
+#if RGFM_HX2P_ABL == 1  // (timing ablation: fragments read once, results wrong)
+  f16x8 af[2][2], bf[NT][2];
+  bool frag_once = false;
+#endif
   auto tap = [&](const char* sArow, const char* sBt, auto kx_tag) {
     constexpr int KX = decltype(kx_tag)::value;
+#if RGFM_HX2P_ABL == 1
+    if (!frag_once) {
+      frag_once = true;
+#else
     f16x8 af[2][2], bf[NT][2];
     {
+#endif
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       af[mt][0] = *reinterpret_cast<const f16x8*>(sArow + aofs[mt][KX][0]);
@@ -521,8 +592,12 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
   // weights of unit g + 2 -> registers; halo items j % 3 == U of chunk c + 1 -> LDS, of chunk c + 2 -> registers.
   // U is a compile-time constant: the item list of a unit is static and its stores / transforms / fetches sit in
   // straight-line code (only block-uniform scalar branches around whole items).
+#ifdef RGFM_HX2P_PROF
+  long long st_begin = 0, st_end = 0, st_a = 0, st_b = 0, st_c = 0;
+#endif
   auto stage = [&](int c, auto u_tag, int gidx) {
     constexpr int U = decltype(u_tag)::value;
+    PPROF_T(ts0);
     // Order: (1) LDS reads the phase needs (descriptor of chunk c + 2, scale/shift pairs of this unit's items) ahead of
     // every store; (2) every consumer of a fetched register; (3) every new fetch, the halo's first.  hipcc cannot
     // count loads across the loop's back edge and waits for vmcnt(0) before the first use (or re-use) of a register
@@ -541,22 +616,42 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
         if (j < nitems) table_a(c + 1, j, e0[k], e1[k]);
       }
     }
+#if RGFM_HX2P_ABL != 4
     if (gidx + 1 < G) commit_b(gidx + 1);
+#endif
+    PPROF_T(tsa);
+#if RGFM_HX2P_ABL == 6
+    if (false) {
+#else
     if (have1) {
+#endif
 #pragma unroll
       for (int k = 0; k < NU; ++k) {
         const int j = (U < 0) ? k : U + 3 * k;
-        if (j < nitems) commit_a(c + 1, j, xf, e0[k], e1[k]);
+        if (j < nitems) commit_a(c + 1, j, RGFM_HX2P_ABL == 3 ? false : xf, e0[k], e1[k]);
       }
     }
+    PPROF_T(tsb);
+#if RGFM_HX2P_ABL == 5
+    if (false) {
+#else
     if (have2) {
+#endif
 #pragma unroll
       for (int k = 0; k < NU; ++k) {
         const int j = (U < 0) ? k : U + 3 * k;
         if (j < nitems) issue_a(dn, j);
       }
     }
+    PPROF_T(tsc);
+#if RGFM_HX2P_ABL != 5
     if (gidx + 2 < G) issue_b(gidx + 2);
+#endif
+    PPROF_T(ts1);
+    PPROF_ADD(grp * 4 + 1, ts0, ts1);
+#ifdef RGFM_HX2P_PROF
+    st_begin = ts0, st_end = ts1, st_a = tsa, st_b = tsb, st_c = tsc;
+#endif
   };
   using U0 = std::integral_constant<int, 0>;
   using U1 = std::integral_constant<int, 1>;
@@ -613,20 +708,26 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
     frag(sArow, sBu + TAPB, K1{}, af1, bf1);
     mfma_tap(af0, bf0);
     HX2P_SEG();
+#if RGFM_HX2P_ABL != 4 && RGFM_HX2P_ABL != 2
 #pragma unroll
     for (int j = 0; j < NB; ++j) *reinterpret_cast<f32x4*>(sBn + boff[j]) = rb[j];
-    commit_a(c + 1, U, true, e0[0], e1[0]);
+#endif
+#if RGFM_HX2P_ABL != 6 && RGFM_HX2P_ABL != 2
+    commit_a(c + 1, U, RGFM_HX2P_ABL != 3, e0[0], e1[0]);
 #pragma unroll
     for (int k = 1; k < NU; ++k)
       if (U + 3 * k < nitems) {
         table_a(c + 1, U + 3 * k, e0[k], e1[k]);
-        commit_a(c + 1, U + 3 * k, true, e0[k], e1[k]);
+        commit_a(c + 1, U + 3 * k, RGFM_HX2P_ABL != 3, e0[k], e1[k]);
       }
+#endif
+#if RGFM_HX2P_ABL != 5 && RGFM_HX2P_ABL != 2
 #pragma unroll
     for (int k = 0; k < NU; ++k)
       if (k == 0 || U + 3 * k < nitems) issue_a(dn, U + 3 * k);
 #pragma unroll
     for (int j = 0; j < NB; ++j) rb[j] = *(const hx_gf32x4*)(wsrc + soff[j]);
+#endif
     frag(sArow, sBu + 2 * TAPB, K2{}, af0, bf0);
     mfma_tap(af1, bf1);
     HX2P_SEG();
@@ -667,30 +768,76 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
     constexpr int U = decltype(u_tag)::value;
     const char* sAc = smemp + (c & 1) * abytes;
     const char* sBu = sB + (gidx & 1) * UB;
+#if RGFM_HX2P_ABL != 2  // (timing ablation 2: no staging in the loop, results wrong)
     if (role == 0) stage(c, u_tag, gidx);
+#endif
+    PPROF_T(tm0);
     const char* sArow = sAc + U * WR * HRW;
+#if RGFM_HX2P_PRIO
+    // waves 4-7 multiply first: their MFMAs go ahead of those of waves 0-3 (which arrive from their staging while
+    // this phase is still running), so that THEIR staging then runs beside the partner's remaining MFMAs
+    if (role != 0) __builtin_amdgcn_s_setprio(RGFM_HX2P_PRIO);
+#endif
     tap(sArow, sBu, K0{});
     tap(sArow, sBu + TAPB, K1{});
     tap(sArow, sBu + 2 * TAPB, K2{});
+#if RGFM_HX2P_PRIO
+    if (role != 0) __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef RGFM_HX2P_PROF
+    asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[1][NT - 1][15]));
+#endif
+    PPROF_T(tm1);
+#if RGFM_HX2P_ABL != 2
     if (role != 0) stage(c, u_tag, gidx);
+#endif
+    PPROF_T(tm2);
     if (gidx != G - 1) __syncthreads();
+    PPROF_T(tm3);
+    PPROF_ADD(grp * 4 + 2, tm0, tm1);
+    PPROF_ADD(grp * 4 + 3, tm2, tm3);
+#ifdef RGFM_HX2P_PROF
+    if (blockIdx.x == 3 && seg == 0 && lane == 0 && gidx < 63) {
+      long long* tr = g_hx2p_trace[grp][gidx];
+      tr[0] = st_begin, tr[1] = st_end, tr[2] = tm0, tr[3] = tm1, tr[4] = tm2, tr[5] = tm3, tr[6] = st_a, tr[7] = st_b, tr[8] = st_c;
+    }
+#endif
     ++gidx;
   };
   int c0 = 0;
-  if (gn_on && nitems >= 3) {
+  if constexpr (CW) {
+    // chunk-sized units: stage everything of chunk c + 1 (all halo items, nine taps of weights), multiply chunk c's nine
+    // taps, ONE barrier; the two waves of a SIMD at opposite ends as in unit()
+#pragma unroll 1
+    for (; c0 < nmain; ++c0) {
+      const char* sAc = smemp + (c0 & 1) * abytes;
+      const char* sBu = sB + (gidx & 1) * UB;
+      if (role == 0) stage(c0, UA{}, gidx);
+      tap(sAc, sBu, K0{}), tap(sAc, sBu + TAPB, K1{}), tap(sAc, sBu + 2 * TAPB, K2{});
+      tap(sAc + WR * HRW, sBu + 3 * TAPB, K0{}), tap(sAc + WR * HRW, sBu + 4 * TAPB, K1{}), tap(sAc + WR * HRW, sBu + 5 * TAPB, K2{});
+      tap(sAc + 2 * WR * HRW, sBu + 6 * TAPB, K0{}), tap(sAc + 2 * WR * HRW, sBu + 7 * TAPB, K1{}),
+          tap(sAc + 2 * WR * HRW, sBu + 8 * TAPB, K2{});
+      if (role != 0) stage(c0, UA{}, gidx);
+      if (gidx != G - 1) __syncthreads();
+      ++gidx;
+    }
+  }
+#if RGFM_HX2P_FAST
+  if (!CW && !(RGFM_HX2P_QEXP && NT == 1 && CFG == HX2P_PAIRN) && gn_on && nitems >= 3) {
 #pragma unroll 1
     for (; c0 < nmain - 1; ++c0) {
       unit_fast(c0, U0{});
       unit_fast(c0, U1{});
       unit_fast(c0, U2{});
     }
-    if (nskip == 0) {
+    if (RGFM_HX2P_TAIL && nskip == 0) {
       unit_tail(c0, U0{});
       unit_tail(c0, U1{});
       unit_tail(c0, U2{});
       ++c0;
     }
   }
+#endif
 #pragma unroll 1
   for (int c = c0; c < nmain; ++c) {
     unit(c, U0{});
@@ -711,6 +858,7 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
       if (gidx != G - 1) __syncthreads();
     }
   }
+  PPROF_T(te0);
   {
     const float qinv = nskip ? a.hq_skip[1] : a.hq[1];
 #pragma unroll
@@ -771,7 +919,7 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
           pix = (unsigned)((bw * (2 * H) + 2 * rr + py) * (2 * W) + 2 * xx + px);
         }
         float* op = a.out + (size_t)(__umul24(pix, (unsigned)a.Cout) + (unsigned)(n0 + l31));
-        if (valid) {
+        if (valid && (RGFM_HX2P_ABL != 7 || acc[mt][0][r] == 1.2345f)) {  // (ablation 7: no output stores)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) op[nt * 32] = acc[mt][nt][r];
         }
@@ -832,15 +980,25 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
   if (full_seg) epilogue(std::true_type{});
   else epilogue(std::false_type{});
 
+#ifdef RGFM_HX2P_PROF
+  PPROF_T(te1);
+  PPROF_ADD(8, te0, te1);
+  if (lane == 0) {
+    for (int i = 0; i < 4; ++i) atomicAdd(&g_hx2p_prof[wave * 4 + i], (unsigned long long)pacc[grp * 4 + i]);
+    if (tid == 0) atomicAdd(&g_hx2p_prof[32], (unsigned long long)pacc[8]), atomicAdd(&g_hx2p_prof[33], 1ull);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------- host side
 static int hx2p_halo(const ConvArgs& a) { return a.g.spt * (a.g.th + 2) * (a.g.W + 2); }
+static int g_hx2p_q = 0;  // RGFM_HX2P_QEXP builds: Cout == 64 layers as NT = 1 HX2P_PAIRN workgroups
+void conv_hx2p_set_q(int v) { g_hx2p_q = v; }
 static size_t hx2p_lds_bytes(const ConvArgs& a, int cfg) {
-  const bool halfc = cfg == HX2P_PAIRN_HALF;
-  const int nt = halfc ? 1 : ((a.Cout % 64 == 0) ? 2 : 1);
+  const bool halfc = cfg == HX2P_PAIRN_HALF || cfg == HX2P_PAIRN_HALF_C;
+  const int nt = (halfc || (RGFM_HX2P_QEXP && g_hx2p_q && cfg == HX2P_PAIRN && a.Cout == 64)) ? 1 : ((a.Cout % 64 == 0) ? 2 : 1);
   const int na = cfg == HX2P_TWO_TILES ? 2 : 1, nbt = 32 * nt * ((cfg == HX2P_PAIRN || halfc) ? 2 : 1);
-  const int tpu = 3;
+  const int tpu = cfg == HX2P_PAIRN_HALF_C ? 9 : 3;
   size_t bytes = (size_t)2 * (na * hx2p_halo(a) + 1) * HRW + (size_t)2 * tpu * nbt * HRW;  // two halo buffers (+ pad record) + two weight units
   if (a.gn_stats0 || a.ab) bytes += (size_t)(na * a.g.spt + 1) * (a.C0 + a.C1) * 2 * sizeof(float);  // scale/shift table + the zero row
   bytes += (size_t)(a.C0 + a.C1 + (a.res_mode == 2 ? a.R0 + a.R1 : 0));                    // 16 bytes per 16-channel chunk: descriptors
@@ -859,18 +1017,32 @@ void conv_hx2p_set_w4(int v) { g_hx2p_w4 = v; }
 // launches with fewer workgroups than this are cut finer (0: never); the CU count
 static int g_hx2p_half = 256;
 void conv_hx2p_set_half(int v) { g_hx2p_half = v; }
+#ifdef RGFM_HX2P_CHUNK_EXP
+static int g_hx2p_chunk = 1;  // 0: no chunk-sized units (HX2P_PAIRN_HALF_C) -- kbench A/B
+#else
+static int g_hx2p_chunk = 0;  // (the instantiations exist in kbench builds only)
+#endif
+void conv_hx2p_set_chunk(int v) {
+#ifdef RGFM_HX2P_CHUNK_EXP
+  g_hx2p_chunk = v;
+#else
+  (void)v;
+#endif
+}
 static int hx2p_cfg(const ConvArgs& a) {
   const bool fits = hx2p_lds_bytes(a, HX2P_FOUR_WAVES) <= 80 * 1024;  // two workgroups per CU
   if (g_hx2p_w4 == 2 && fits) return HX2P_FOUR_WAVES;
   if (g_hx2p_w4 == 1 && fits && a.Cout % 128 != 0) return HX2P_FOUR_WAVES;
   const int tiles = geom_num_tiles(a.g, a.B);
+  if (RGFM_HX2P_QEXP && g_hx2p_q && a.Cout == 64) return HX2P_PAIRN;
   if (a.Cout % 128 != 0) {
     const int wgs = ((tiles + 1) / 2) * (a.Cout / (32 * ((a.Cout % 64 == 0) ? 2 : 1)));
     return (g_hx2p_half && wgs < g_hx2p_half) ? HX2P_FOUR_WAVES : HX2P_TWO_TILES;
   }
   const int wgs = tiles * (a.Cout / 128);
   if (!(g_hx2p_half && wgs < g_hx2p_half)) return HX2P_PAIRN;
-  return HX2P_PAIRN_HALF;
+  // chunk-sized units where their weight buffers fit beside the halo (the 8x8 level; 16x16 at small batches)
+  return (g_hx2p_chunk && hx2p_lds_bytes(a, HX2P_PAIRN_HALF_C) <= 160 * 1024) ? HX2P_PAIRN_HALF_C : HX2P_PAIRN_HALF;
 }
 
 // the pipelined kernel takes: stride-1 / upsampling convs whose input norm (if any) is the consumer-side one
@@ -888,7 +1060,13 @@ int conv_hx2p_init() {
   RAISEP(1, CONV_S1, HX2P_TWO_TILES); RAISEP(1, CONV_UP2, HX2P_TWO_TILES);
   RAISEP(2, CONV_S1, HX2P_TWO_TILES); RAISEP(2, CONV_UP2, HX2P_TWO_TILES);
   RAISEP(2, CONV_S1, HX2P_PAIRN); RAISEP(2, CONV_UP2, HX2P_PAIRN);
+#if RGFM_HX2P_QEXP
+  RAISEP(1, CONV_S1, HX2P_PAIRN); RAISEP(1, CONV_UP2, HX2P_PAIRN);
+#endif
   RAISEP(1, CONV_S1, HX2P_PAIRN_HALF); RAISEP(1, CONV_UP2, HX2P_PAIRN_HALF);
+#ifdef RGFM_HX2P_CHUNK_EXP
+  RAISEP(1, CONV_S1, HX2P_PAIRN_HALF_C); RAISEP(1, CONV_UP2, HX2P_PAIRN_HALF_C);
+#endif
   RAISEP(1, CONV_S1, HX2P_FOUR_WAVES); RAISEP(1, CONV_UP2, HX2P_FOUR_WAVES);
   RAISEP(2, CONV_S1, HX2P_FOUR_WAVES); RAISEP(2, CONV_UP2, HX2P_FOUR_WAVES);
 #undef RAISEP
@@ -901,9 +1079,9 @@ void launch_conv_hx2p(const ConvArgs& a_in, int mode, hipStream_t s) {
   const int nt = (a.Cout % 64 == 0) ? 2 : 1;
   const int tiles = geom_num_tiles(a.g, a.B);
   const int cfg = hx2p_cfg(a);
-  if (cfg == HX2P_PAIRN_HALF) a.fin_expected *= 2;  // (producer-side finalize: twice the 4-wave groups along the channels arrive)
+  if (cfg == HX2P_PAIRN_HALF || cfg == HX2P_PAIRN_HALF_C) a.fin_expected *= 2;  // (producer-side finalize: twice the 4-wave groups along the channels arrive)
   dim3 grid(cfg == HX2P_TWO_TILES ? (tiles + 1) / 2 : tiles,
-            cfg == HX2P_PAIRN ? a.Cout / 128 : (cfg == HX2P_PAIRN_HALF ? a.Cout / 64 : a.Cout / (32 * nt)), 1);
+            cfg == HX2P_PAIRN ? a.Cout / 128 : ((cfg == HX2P_PAIRN_HALF || cfg == HX2P_PAIRN_HALF_C) ? a.Cout / 64 : a.Cout / (32 * nt)), 1);
   const size_t lds = hx2p_lds_bytes(a, cfg);
 #define LAUNCHP(NTV, M, P) hipLaunchKernelGGL((conv_mfma_hx2p_kernel<NTV, M, P>), grid, dim3(P == HX2P_FOUR_WAVES ? 256 : 512), lds, s, a, tiles)
 #define LAUNCHM(NTV, P)                           \
@@ -911,8 +1089,17 @@ void launch_conv_hx2p(const ConvArgs& a_in, int mode, hipStream_t s) {
     if (mode == CONV_S1) LAUNCHP(NTV, CONV_S1, P); \
     else LAUNCHP(NTV, CONV_UP2, P);               \
   } while (0)
+#if RGFM_HX2P_QEXP
+  if (cfg == HX2P_PAIRN && a.Cout == 64) {
+    grid = dim3(tiles, 1, 1);
+    LAUNCHM(1, HX2P_PAIRN);
+  } else
+#endif
   if (cfg == HX2P_PAIRN) LAUNCHM(2, HX2P_PAIRN);
   else if (cfg == HX2P_PAIRN_HALF) LAUNCHM(1, HX2P_PAIRN_HALF);
+#ifdef RGFM_HX2P_CHUNK_EXP
+  else if (cfg == HX2P_PAIRN_HALF_C) LAUNCHM(1, HX2P_PAIRN_HALF_C);
+#endif
   else if (cfg == HX2P_FOUR_WAVES) {
     if (nt == 2) LAUNCHM(2, HX2P_FOUR_WAVES);
     else LAUNCHM(1, HX2P_FOUR_WAVES);

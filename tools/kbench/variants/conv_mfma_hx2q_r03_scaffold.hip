@@ -1,3 +1,5 @@
+// FROZEN COPY (round 3, commit ef17e0f) of the kernel with its experiment scaffolding -- timing ablations (results wrong by
+// construction), phase stamps, rejected cuts.  tools/kbench only (-DRGFM_KB_SCAFFOLD); the shipped kernel is csrc/'s.
 // conv_mfma_hx2q.hip -- the two-plane fp16 conv (conv_mfma_hx2p.hip's arithmetic, LDS images and summation order, so
 // a row's result is bit for bit the pipelined kernel's) cut for FOUR waves per SIMD and for workgroups that walk
 // SEVERAL tiles with one continuous staging stream.
@@ -25,6 +27,23 @@
 
 namespace rgfm {
 
+#ifndef RGFM_HX2Q_STAGGER
+#define RGFM_HX2Q_STAGGER 1  // 1: waves 4-7 transform + store their halo items AFTER the unit's MFMAs (waves 0-3: before)
+#endif
+#ifndef RGFM_HX2Q_ABL
+#define RGFM_HX2Q_ABL 0      // kbench timing ablations (results wrong): 1 no halo staging in the K loop, 2 nor weight DMA,
+#endif                       // 3 nor fragment reads (MFMAs + barriers only), 4: everything but the MFMAs
+#ifndef RGFM_HX2Q_PRIO
+#define RGFM_HX2Q_PRIO 0     // 1: raised issue priority during a unit's MFMAs
+#endif
+#ifdef RGFM_HX2Q_PROF  // (tools/kbench: phase stamps of wave 0 / wave 4 of every 16th workgroup, summed)
+__device__ unsigned long long g_hx2q_prof[16];
+#define QPROF_T(var) const long long var = __builtin_amdgcn_s_memtime()
+#define QPROF_ACC(i, t0, t1) qacc[i] += (t1) - (t0)
+#else
+#define QPROF_T(var)
+#define QPROF_ACC(i, t0, t1)
+#endif
 
 // SKIP: res_mode == 2 (fused 1x1 skip conv: raw one-tap chunks behind the main chunks).  NG: 32-channel groups per
 // workgroup -- 2: 8 waves x <= 128 VGPRs, two workgroups per CU = four waves per SIMD; 1 (Cout = 32: the MNIST net's
@@ -45,6 +64,10 @@ __global__ __launch_bounds__(256 * NG, (NG == 2 && NT == 1) ? 4 : 2) void conv_m
   constexpr int NIT = 6 / NG;               // halo items (pixel, 4 channels) per thread and chunk: ceil(HALO * 4 / NTHR)
   static_assert(HALO * 4 <= NIT * NTHR && HALO * 4 > (NIT - 1) * NTHR - NTHR, "items per thread");
   extern __shared__ __attribute__((aligned(16))) char smq[];
+#ifdef RGFM_HX2Q_PROF
+  long long qacc[3] = {0, 0, 0};
+#endif
+  QPROF_T(tq0);
   char* const sB = smq + 2 * ABYTES;
   float* const sTab = reinterpret_cast<float*>(sB + 2 * UB);  // [nrows + 1][cin][2]: S_A x (scale, shift) per sample, and a zero row
   const int cin = a.C0 + a.C1;
@@ -125,6 +148,7 @@ __global__ __launch_bounds__(256 * NG, (NG == 2 && NT == 1) ? 4 : 2) void conv_m
     }
     for (int i = tid; i < 2 * cin; i += NTHR) sTab[nrows * cin * 2 + i] = 0.f;  // the all-zero row of the padding items
   }
+  QPROF_T(tq1);
 
   const int nmain = cin / KC;
   const int nskip = SKIP ? (a.R0 + a.R1) / KC : 0;
@@ -285,6 +309,7 @@ __global__ __launch_bounds__(256 * NG, (NG == 2 && NT == 1) ? 4 : 2) void conv_m
   auto next_unit = [&](int u) { return u + 1 == G ? 0 : u + 1; };
 
   __syncthreads();  // the scale/shift table and the chunk descriptors are complete
+  QPROF_T(tq2);
 
   // ---- pipeline fill: halo of the first chunk and weights of unit 0 in LDS, raw halo of the second chunk and weights
   // of unit 1 in registers
@@ -331,6 +356,13 @@ __global__ __launch_bounds__(256 * NG, (NG == 2 && NT == 1) ? 4 : 2) void conv_m
   auto tap = [&](const char* sArow, const char* sBt, int o0) {
     f16x8 af[2][2], bf[NT][2];
     const int o1 = o0 ^ 32;
+#if RGFM_HX2Q_ABL == 3
+    af[0][0] = af[0][1] = af[1][0] = af[1][1] = __builtin_bit_cast(f16x8, ra[0]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bf[nt][0] = bf[nt][1] = af[0][0];
+    (void)sArow, (void)sBt, (void)o1;
+    if (false)
+#endif
     {
     af[0][0] = *reinterpret_cast<const f16x8*>(sArow + o0);
     af[0][1] = *reinterpret_cast<const f16x8*>(sArow + o1);
@@ -343,6 +375,9 @@ __global__ __launch_bounds__(256 * NG, (NG == 2 && NT == 1) ? 4 : 2) void conv_m
     }
     }
     constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#if RGFM_HX2Q_ABL == 4
+    asm volatile("" :: "v"(af[0][0]), "v"(af[0][1]), "v"(af[1][0]), "v"(af[1][1]), "v"(bf[0][0]), "v"(bf[0][1]));
+#else
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
@@ -350,13 +385,20 @@ __global__ __launch_bounds__(256 * NG, (NG == 2 && NT == 1) ? 4 : 2) void conv_m
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt][PA[q]], bf[nt][PB[q]], acc[mt][nt], 0, 0, 0);
+#endif
   };
   auto taps3 = [&](int U) {
     const char* sArow = smq + (gc & 1) * ABYTES + U * WR * HRW;
     const char* sBu = sB + (gu & 1) * UB;
+#if RGFM_HX2Q_PRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
     tap(sArow, sBu, aofs[0]);
     tap(sArow, sBu + TAPB, aofs[1]);
     tap(sArow, sBu + 2 * TAPB, aofs[2]);
+#if RGFM_HX2Q_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   };
   // the weight half of a unit's staging: the next unit's weights -> the other weight buffer (free since the last barrier)
 #define HX2Q_W_STEP()                       \
@@ -372,8 +414,10 @@ __global__ __launch_bounds__(256 * NG, (NG == 2 && NT == 1) ? 4 : 2) void conv_m
     ++gu, u1 = next_unit(u1);               \
   } while (0)
 
+  QPROF_T(tq3);
 #pragma unroll 1
   for (int t = 0; t < ntw; ++t) {
+    QPROF_T(tt0);
     // ---- accumulator init: bias (+ skip bias + time embedding), scaled by q (the accumulators hold q x the true
     // sums); an identity residual enters as fma(res, q, .)
     const int tb = cur.b, tr = cur.r;  // this tile: sample, tile inside the sample
@@ -428,14 +472,26 @@ __global__ __launch_bounds__(256 * NG, (NG == 2 && NT == 1) ? 4 : 2) void conv_m
       }
     }
     if (t == 0) __syncthreads();  // (the fill's stores)
+    QPROF_T(tt1);
     // ---- main chunks: three units each.  Item 0 of the stream's next chunk is stored (and of the one after fetched)
     // in unit 0, items 1 and 2 in unit 1, none in unit 2; the weights FIRST, so that the wait for them at the top of the
     // next unit (vmcnt is in order) leaves the slower halo fetches behind them in flight
     // (the chunk the stream stores next is a main chunk, except behind the last main chunk of a conv with skip chunks)
+#if RGFM_HX2Q_ABL >= 1 && RGFM_HX2Q_ABL <= 3
+#define commit_a(...) ((void)0)
+#define issue_a(...) ((void)0)
+#endif
+#if RGFM_HX2Q_ABL >= 2 && RGFM_HX2Q_ABL <= 3
+#define wdma(...) ((void)0)
+#endif
     auto main_chunk = [&](auto xf_tag) {
       const Pos p1 = succ(cur), p2 = succ(p1);
       (void)p2;
+#if RGFM_HX2Q_STAGGER
       const bool early = NG == 2 ? grp == 0 : ((int)blockIdx.x & 1) == 0;
+#else
+      constexpr bool early = true;
+#endif
       // the halo items of a unit.  NG == 2 (three items): item 0 in unit 0, items 1 and 2 in unit 1, none in unit 2
       // (fewer staging sites: the 128-VGPR budget); NG == 1 (six items): j % 3 == U
       auto commit_items = [&](auto u_tag) {
@@ -513,6 +569,7 @@ __global__ __launch_bounds__(256 * NG, (NG == 2 && NT == 1) ? 4 : 2) void conv_m
       for (int c = 0; c < nskip - 1; ++c) skip_chunk(std::false_type{});
       skip_chunk(std::true_type{});  // (behind the last skip chunk: the next tile's first chunk)
     }
+    QPROF_T(tt2);
     asm volatile("" : "+s"(kp));
     int tid_e = threadIdx.x;
     asm volatile("" : "+v"(tid_e));
@@ -573,11 +630,37 @@ __global__ __launch_bounds__(256 * NG, (NG == 2 && NT == 1) ? 4 : 2) void conv_m
       }
       if (ke.fin_ab) fin_arrive(ke, tb, lane_e, nparts, false);
     }
+    QPROF_T(tt3);
+    QPROF_ACC(0, tt0, tt1);
+    QPROF_ACC(1, tt1, tt2);
+    QPROF_ACC(2, tt2, tt3);
   }
 #undef HX2Q_W_STEP
 #undef HX2Q_U_NEXT
+#if RGFM_HX2Q_ABL >= 1 && RGFM_HX2Q_ABL <= 3
+#undef commit_a
+#undef issue_a
+#endif
+#if RGFM_HX2Q_ABL >= 2 && RGFM_HX2Q_ABL <= 3
+#undef wdma
+#endif
 #undef HX2Q_WDMA_WAIT
   if (!(hmax < HX_BIG)) atomicOr(a.range_flag, 1u);  // (rare) plane h would be >= 32768 (or inf)
+#ifdef RGFM_HX2Q_PROF
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  QPROF_T(tq7);
+  if (lane == 0 && seg == 0 && (blockIdx.x & 15) == 0) {
+    unsigned long long* pp = g_hx2q_prof + grp * 8;
+    atomicAdd(pp + 0, (unsigned long long)(tq1 - tq0));  // GroupNorm table
+    atomicAdd(pp + 1, (unsigned long long)(tq2 - tq1));  // descriptors, offsets, item decode, barrier
+    atomicAdd(pp + 2, (unsigned long long)(tq3 - tq2));  // fill
+    atomicAdd(pp + 3, (unsigned long long)qacc[0]);      // accumulator init (all tiles)
+    atomicAdd(pp + 4, (unsigned long long)qacc[1]);      // K loops
+    atomicAdd(pp + 5, (unsigned long long)qacc[2]);      // epilogues
+    atomicAdd(pp + 6, (unsigned long long)(tq7 - tq0));  // whole workgroup
+    atomicAdd(pp + 7, 1ull);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------- host side
@@ -638,7 +721,9 @@ bool conv_hx2q_supported(const ConvArgs& a, int mode) {
   if ((a.C0 + a.C1) % KC != 0) return false;
   if (a.res_mode == 2 && (a.R0 + a.R1) % KC != 0) return false;
   const Hx2qCut c = hx2q_cut(a);
+#ifndef RGFM_HX2Q_ALL_CUTS
   if (c.nt != 1) return false;
+#endif
   // a workgroup covers one packed weight block (128 / 64 / 32 channels: hx2_block_channels) or half of a 128-channel one
   const int nb = a.Cout % 128 == 0 ? 128 : (a.Cout % 64 == 0 ? 64 : 32);
   if (a.Cout % c.cb() != 0 || !(c.cb() == nb || (c.cb() == 64 && nb == 128))) return false;
@@ -665,9 +750,17 @@ bool conv_hx2q_supported(const ConvArgs& a, int mode) {
 // 2..25 % slower everywhere and {2,2} -- conv_mfma_hx2p's own tile behind the tile stream -- within +-2 %: the stream
 // pays where a tile's K loop is short (Cout <= 64 at 32x32), not where hx2p's interleaved units already hide the
 // per-tile costs.
+#ifdef RGFM_HX2Q_ALL_CUTS
+#define HX2Q_FOR_ALL(X) \
+  X(4, false, 1, 1) X(4, true, 1, 1) X(5, false, 1, 1) X(5, true, 1, 1) \
+  X(4, false, 2, 1) X(4, true, 2, 1) X(5, false, 2, 1) X(5, true, 2, 1) \
+  X(4, false, 1, 2) X(4, true, 1, 2) X(5, false, 1, 2) X(5, true, 1, 2) \
+  X(4, false, 2, 2) X(4, true, 2, 2) X(5, false, 2, 2) X(5, true, 2, 2)
+#else
 #define HX2Q_FOR_ALL(X) \
   X(4, false, 1, 1) X(4, true, 1, 1) X(5, false, 1, 1) X(5, true, 1, 1) \
   X(4, false, 2, 1) X(4, true, 2, 1) X(5, false, 2, 1) X(5, true, 2, 1)
+#endif
 
 int conv_hx2q_init() {
   int rc = 0;

@@ -9,7 +9,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="--no-cpu-baseline --no-alt-mode --no-arith-check"
+B="--no-cpu-baseline --no-alt-mode --no-arith-check --no-parity-check"
 
 # 1. the official line (default flags: cpu_baseline, alternative mode, arithmetic check all on)
 ( cd $R && timeout -k 10 900 python3 bench.py > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench_err.txt ) || exit 1
