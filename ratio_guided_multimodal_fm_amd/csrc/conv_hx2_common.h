@@ -49,6 +49,67 @@ __device__ __forceinline__ float silu_scaled(float zs) {
 // (HX_SMALL / hx_small_flag, the low side of the raw staging path, live in rgfm_device.h: the bf16x3 and fp32 kernels
 // check it too when they produce a tensor that a two-plane conv stages raw)
 
+// ---- "P format": an activation ALREADY normalised, activated and split, as the consumer's MFMAs read it
+// (conv_mfma_hx2d.hip stages it by LDS-DMA only).  One (pixel, 16-channel chunk) = 64 B:
+//   [plane h: channels 0 .. 15 | plane l: channels 0 .. 15]  fp16 of S_A silu(scale x + shift),   [B][H][W][C / 16][64 B]
+// -- the bytes of the fp32 map it replaces.  Written by the producing conv's epilogue where a workgroup owns whole
+// (sample, GroupNorm group) sets (ConvArgs::pout), or by launch_hx_presplit.
+
+// exchange between the two lanes of a channel pair (2 k, 2 k + 1): DPP quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ float hx_swap1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+
+// GroupNorm scale / shift (x S_A) of this lane's channel from its (mean, M2) over n pixels, when all `cpg` channels of
+// its group sit in consecutive lanes of ONE wave (cpg a power of two <= 32; both lane halves hold the same values).
+// The consumer-side prologue's formula (fp64: N, sum n mean, sum M2 + n mean^2 -> mean, var), here with one channel per
+// lane and a butterfly over the group's lanes.
+// (hx_group_affine_s: from the channel's sums s1 = sum n_p mean_p, s2 = sum M2_p + n_p mean_p^2 over its parts, n pixels in all)
+__device__ __forceinline__ void hx_group_affine_s(double s1, double s2, double n, int cpg, float gamma, float beta, float& sc, float& sh) {
+  for (int o = 1; o < cpg; o <<= 1) s1 += __shfl_xor(s1, o), s2 += __shfl_xor(s2, o);
+  const double N = n * (double)cpg, mean = s1 / N, var = s2 / N - mean * mean;
+  const float rstd = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + 1e-5));
+  const float a = rstd * gamma;
+  sc = HX_SA * a;
+  sh = HX_SA * (beta - (float)mean * a);
+}
+__device__ __forceinline__ void hx_group_affine(float mean_c, float m2_c, float n, int cpg, float gamma, float beta, float& sc, float& sh) {
+  double s1 = (double)n * (double)mean_c, s2 = (double)m2_c + (double)n * (double)mean_c * (double)mean_c;
+  for (int o = 1; o < cpg; o <<= 1) s1 += __shfl_xor(s1, o), s2 += __shfl_xor(s2, o);
+  const double N = (double)n * (double)cpg, mean = s1 / N, var = s2 / N - mean * mean;
+  const float rstd = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + 1e-5));
+  const float a = rstd * gamma;
+  sc = HX_SA * a;
+  sh = HX_SA * (beta - (float)mean * a);
+}
+
+// One wave's 64 pixels x 32 channels (accumulator layout: channel = lane & 31, acc<mt>[r] = pixel 32 mt + (r & 3) +
+// 8 (r >> 2) + 4 (lane >> 5) of the block) as P records: S_A silu(sc x + sh), split, two channels per lane -- the lanes of a
+// channel pair trade one value of every pixel pair, so each holds (2 k, 2 k + 1) of ONE pixel -- and one 4-byte store per
+// plane.  rec0: the record of (pixel 0 of the block, this lane's chunk); pstride: bytes per pixel (C / 16 x 64).
+// Returns the largest |S_A silu(.)| seen (the caller raises range-flag bit 0 on >= HX_BIG, as the staging paths do).
+__device__ __forceinline__ float hx_p_emit(const f32x16& acc0, const f32x16& acc1, float sc, float sh, char* rec0, unsigned pstride, int l31, int hp) {
+  const bool odd = (l31 & 1) != 0;
+  char* const base = rec0 + ((l31 & 15) >> 1) * 4 + (size_t)(4 * hp + (odd ? 1 : 0)) * pstride;
+  float m = 0.f;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const f32x16& am = mt ? acc1 : acc0;
+      const float o0 = silu_scaled(fmaf(sc, am[r], sh)), o1 = silu_scaled(fmaf(sc, am[r + 1], sh));
+      const float recv = hx_swap1(odd ? o0 : o1);
+      const float lo = odd ? recv : o0, hi = odd ? o1 : recv;
+      m = hx_absmax3(lo, hi, m);
+      unsigned ph, pl;
+      hsplit2(lo, hi, ph, pl);
+      char* const q = base + (size_t)(32 * mt + (r & 3) + 8 * (r >> 2)) * pstride;
+      *reinterpret_cast<unsigned*>(q) = ph;
+      *reinterpret_cast<unsigned*>(q + 32) = pl;
+    }
+  return m;
+}
+
 constexpr int HRW = 64;  // bytes per LDS record: [plane h | plane l] x 16 fp16
 // byte offset of 16-byte slot (plane, half) inside record `rec`
 __device__ __forceinline__ int hswz(int rec, int plane, int half) { return (((2 * plane + half) ^ (rec >> 2)) & 3) * 16; }

@@ -396,14 +396,16 @@ __global__ __launch_bounds__(512, 1) void conv_mfma_hx2c_kernel(const ConvArgs a
     hx_small_flag(a.range_flag, m);
   }
   const size_t pix0 = (size_t)sample * (W * W);
+  if (a.out) {
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int p = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hp;
-      a.out[(pix0 + p) * a.Cout + ch0] = acc[mt][r];
-    }
-  if (a.stats_out) {
+      for (int r = 0; r < 16; ++r) {
+        const int p = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hp;
+        a.out[(pix0 + p) * a.Cout + ch0] = acc[mt][r];
+      }
+  }
+  if (a.stats_out || a.pout) {
     float s = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -420,7 +422,17 @@ __global__ __launch_bounds__(512, 1) void conv_mfma_hx2c_kernel(const ConvArgs a
         m2 += d * d;
       }
     m2 += __shfl_xor(m2, 32);
-    if (hp == 0) store_stats(a, a.stats_out + ((size_t)sample * a.g.nparts * a.Cout + ch0) * 2, mean, m2);
+    if (a.stats_out && hp == 0) store_stats(a, a.stats_out + ((size_t)sample * a.g.nparts * a.Cout + ch0) * 2, mean, m2);
+    if (a.pout) {
+      // P format for the norm that consumes this output (ConvArgs::pout): a wave holds a whole sample x 32 channels, i.e.
+      // whole GroupNorm groups (Cout / 8 = 8, 16 or 32 channels), so the norm's statistics are finished right here
+      float sc, sh;
+      hx_group_affine(mean, m2, 64.f, a.Cout >> 3, a.pn_gamma[ch0], a.pn_beta[ch0], sc, sh);
+      const unsigned pstride = (unsigned)a.Cout * 4u;
+      char* const rec0 = reinterpret_cast<char*>(a.pout) + pix0 * pstride + (size_t)(ch0 >> 4) * 64;
+      const float pm = hx_p_emit(acc[0], acc[1], sc, sh, rec0, pstride, l31, hp);
+      if (!(pm < HX_BIG)) atomicOr(a.range_flag, 1u);
+    }
   }
 }
 
@@ -445,6 +457,7 @@ bool conv_hx2c_supported(const ConvArgs& a, int mode) {
   if (a.res_mode == 2 && (a.R0 + a.R1) % KC != 0) return false;
   if (a.res_mode == 1 && a.R0 != a.Cout) return false;
   if (a.ep_scale || a.fin_ab) return false;
+  if (a.pout && (a.Cout != 64 && a.Cout != 128 && a.Cout != 256)) return false;  // (whole power-of-two groups per wave)
   if (hx2c_lds_bytes(a) > 160 * 1024) return false;
   // Where it pays (tools/kbench/scripts/q23.sh, q24.sh): 128 -> 128 and 256 -> 128 without a fused skip -3 ... -8 % against
   // conv_mfma_hx2p_kernel at 32 ... 512 rows; with the 1x1 skip (16 one-tap chunks, each behind a whole chunk of staging)

@@ -355,9 +355,360 @@ __global__ __launch_bounds__(512, 1) void conv_mfma_hx2d_kernel(const ConvArgs a
   }
 }
 
+// ---------------------------------------------------------------- four waves, two workgroups per CU
+// conv_mfma_hx2d4_kernel: the same conv cut for the LDS.  The eight-wave kernel above reads 1 KB of fragments per MFMA (a
+// wave tile of 64 pixels x 32 channels: four A and two B reads per six MFMAs) -- with the DMA writes the LDS is busy ~70 % of a
+// chunk's MFMA time, and its chunk takes 1.9 - 2.9 us where the matrix work is 1.45 (tools/kbench, round 4).  Here a wave
+// owns 64 pixels x 64 channels (NT = 2: eight reads per twelve MFMAs, 0.67 KB per MFMA), a workgroup is FOUR waves = one
+// tile x 64 channels, and the weights are double-buffered per UNIT of three taps (12 KB) instead of per chunk, so that a
+// workgroup needs <= 80 KB and TWO share a CU: the two waves of a SIMD belong to different workgroups with their own
+// barriers, and one's barrier / DMA-issue gaps fall under the other's MFMAs.
+template <int W, bool SKIP>
+__global__ __launch_bounds__(256, 2) void conv_mfma_hx2d4_kernel(const ConvArgs a, const int num_tiles) {
+  constexpr int SPT = W == 8 ? 4 : 1, H = W, WR = W + 2, HR = H + 2;
+  constexpr int PREC = WR * HR, HALO = SPT * PREC;
+  constexpr int NPC = (HALO + 15) / 16;             // 25 / 21 one-KB pieces per chunk
+  constexpr int ABYTES = NPC * 1024;
+  constexpr int NTHR = 256, NW = 4, CB = 64;
+  constexpr int TAPB = CB * HRW, UB = 3 * TAPB, PPT = TAPB / 1024;  // a tap's slab 4 KB, a unit 12 KB
+  constexpr int NPH = (NPC + NW - 1) / NW;          // halo pieces per wave and chunk: 7 / 6
+  constexpr int NPU = 3 * PPT / NW;                 // weight pieces per wave and unit: 3
+  constexpr int RPS = 64 / W;
+  constexpr int MT_OFF = (RPS / 2) * WR * HRW;
+  constexpr int SWZ = 1;
+  extern __shared__ __attribute__((aligned(16))) char smd4[];
+  char* const sA = smd4;
+  char* const sB = smd4 + 2 * ABYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, seg = tid >> 6;
+  const int l31 = lane & 31, hp = lane >> 5;
+  const int tile = blockIdx.x, cb = blockIdx.y;
+  const int b0 = tile * SPT;
+  const int nmain = a.C0 / KC;
+  const int wave_s = __builtin_amdgcn_readfirstlane(seg);
+
+  unsigned soff[NPH];
+  bool sval[NPH];
+#pragma unroll
+  for (int j = 0; j < NPH; ++j) {
+    const int pq = seg + NW * j;
+    const int pc = pq < NPC ? pq : pq - NPC;
+    const int rec = pc * 16 + (lane >> 2);
+    const int s = rec / PREC, rr = rec - s * PREC;
+    const int hy = rr / WR, hx = rr - hy * WR;
+    const int y = hy - 1, x = hx - 1;
+    const int logical = ((lane & 3) ^ (hx >> SWZ)) & 3;
+    sval[j] = rec < HALO && y >= 0 && y < H && x >= 0 && x < W && b0 + s < a.B;
+    soff[j] = sval[j] ? (unsigned)((((b0 + s) * H + y) * W + x) * nmain) * 64u + (unsigned)logical * 16u : 0u;
+  }
+  const char* const pin = reinterpret_cast<const char*>(a.pin0);
+  const char* const zeros = reinterpret_cast<const char*>(a.zeros) + (lane & 3) * 16;
+  const unsigned sA_lds = (unsigned)(size_t)sA, sB_lds = (unsigned)(size_t)sB;
+  auto dma = [&](const char* gsrc, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+  };
+  auto hdma1 = [&](int c, int j) {  // halo piece j (0 .. NPH - 1) of this wave, chunk c
+    const int pq = wave_s + NW * j;
+    const int pc = pq < NPC ? pq : pq - NPC;
+    dma(sval[j] ? pin + (size_t)soff[j] + (size_t)c * 64 : zeros, sA_lds + (unsigned)((c & 1) * ABYTES + pc * 1024));
+  };
+
+  // ---- weights.  Unit g < 3 nmain: kernel row g % 3 of main chunk g / 3 (three consecutive taps of the packed image);
+  // g >= 3 nmain: the one tap of skip chunk g - 3 nmain.  Unit g lives in weight buffer g & 1.
+  const int nskip = SKIP ? (a.R0 + a.R1) / KC : 0;
+  const int G = 3 * nmain + nskip;
+  const bool nb128 = (a.Cout & 127) == 0;
+  const int TAPS = nb128 ? 2 * TAPB : TAPB;
+  const int wblk = nb128 ? cb >> 1 : cb, whalf = nb128 ? (cb & 1) * TAPB : 0;
+  const char* const wpk = reinterpret_cast<const char*>(a.wpkh) + (size_t)wblk * nmain * 9 * TAPS + whalf;
+  const char* const wsk = reinterpret_cast<const char*>(SKIP ? a.wskiph : a.wpkh) + (size_t)wblk * nskip * TAPS + whalf;
+  auto wdma1 = [&](int g, int j) {  // weight piece j (0 .. NPU - 1) of this wave, unit g
+    const bool main = !SKIP || g < 3 * nmain;
+    const int pq = wave_s + NW * j;                  // 0 .. 11: tap pq / 4, KB pq % 4 of the unit
+    const int pc = main ? pq : (pq & (PPT - 1));     // (a skip unit is one tap: every wave repeats its KB)
+    const char* src = main ? wpk + (size_t)g * 3 * TAPS : wsk + (size_t)(g - 3 * nmain) * TAPS;
+    dma(src + (pc / PPT) * TAPS + (pc % PPT) * 1024 + lane * 16, sB_lds + (unsigned)((g & 1) * UB + pc * 1024));
+  };
+
+  // ---- the 1x1 skip's raw sources (SKIP): centre records through registers, as in the eight-wave kernel
+  constexpr int NIS = SKIP ? (SPT * H * W * 4) / NTHR : 1;  // 4
+  unsigned spix[NIS];
+  int sdst[NIS];
+  bool sok[NIS];
+  const int q4 = tid & 3;
+  if (SKIP) {
+#pragma unroll
+    for (int j = 0; j < NIS; ++j) {
+      const int it = tid + NTHR * j, px = it >> 2;
+      const int s = px / (H * W), pr = px - s * (H * W);
+      const int y = pr / W, x = pr - y * W;
+      const int rec = s * PREC + (y + 1) * WR + (x + 1);
+      sdst[j] = rec * HRW + ((((q4 >> 1) ^ ((x + 1) >> SWZ)) & 3) * 16) + (q4 & 1) * 8;
+      sok[j] = b0 + s < a.B;
+      spix[j] = sok[j] ? (unsigned)((b0 + s) * (H * W) + pr) : 0u;
+    }
+  }
+  f32x4 rs0[NIS], rs1[NIS];
+  float hmax = 0.f;
+  auto sissue = [&](f32x4 (&ra)[NIS], int k) {
+    const int c = k * KC;
+    const bool first = c < a.R0;
+    const float* src = first ? a.res0 + c : a.res1 + (c - a.R0);
+    const unsigned cs = (unsigned)(first ? a.R0 : a.R1);
+#pragma unroll
+    for (int j = 0; j < NIS; ++j) ra[j] = *(const hx_gf32x4*)(src + (size_t)(__umul24(spix[j], cs) + (unsigned)(q4 * 4)));
+  };
+  auto scommit = [&](const f32x4 (&ra)[NIS], int pos) {  // into halo buffer pos & 1
+    char* base = sA + (pos & 1) * ABYTES;
+#pragma unroll
+    for (int j = 0; j < NIS; ++j) {
+      const float sa = sok[j] ? HX_SA : 0.f;
+      const f32x4 v = ra[j];
+      f32x4 o;
+      o.x = v.x * sa, o.y = v.y * sa, o.z = v.z * sa, o.w = v.w * sa;
+      unsigned h0, l0, h1, l1;
+      hsplit2(o.x, o.y, h0, l0);
+      hsplit2(o.z, o.w, h1, l1);
+      hmax = hx_absmax3(o.x, o.y, hmax);
+      hmax = hx_absmax3(o.z, o.w, hmax);
+      const hx_u32x2 ph = {h0, h1}, pl = {l0, l1};
+      *reinterpret_cast<hx_u32x2*>(base + sdst[j]) = ph;
+      *reinterpret_cast<hx_u32x2*>(base + (sdst[j] ^ 32)) = pl;
+    }
+  };
+
+  // ---- fragment offsets
+  int aofs[3];
+  {
+    const int r = l31 / W, x = l31 % W;
+    const int arec = (SPT == 4 ? seg * PREC : seg * RPS * WR) + r * WR + x;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) aofs[kx] = (arec + kx) * HRW + ((hp ^ (((x + kx) >> SWZ) & 3)) & 3) * 16;
+  }
+  int bofs[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int rec = nt * 32 + l31;
+    bofs[nt] = rec * HRW + ((hp ^ (rec >> 2)) & 3) * 16;
+  }
+
+  // ---- pipeline fill: chunk 0's halo and unit 0's weights on their way
+#pragma unroll
+  for (int j = 0; j < NPH; ++j) hdma1(0, j);
+#pragma unroll
+  for (int j = 0; j < NPU; ++j) wdma1(0, j);
+  if (SKIP) {
+    sissue(rs0, 0);
+    if (nskip > 1) sissue(rs1, 1);
+  }
+
+  // ---- accumulators
+  const float qmain = a.hq[0];
+  const int sample = SPT == 4 ? b0 + seg : b0;
+  const int part = SPT == 4 ? 0 : seg;
+  const int ch0 = cb * CB + l31;  // (+ 32 nt)
+  const size_t pix0 = (size_t)sample * (H * W) + (SPT == 4 ? 0 : seg * 64);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int ch = ch0 + 32 * nt;
+    float v = a.bias[ch];
+    if (SKIP) v += a.skip_bias[ch];
+    if (a.temb) v += a.temb[((size_t)(a.temb_per_row ? (sample < a.B ? sample : 0) : 0) + (a.step_ptr ? (size_t)*a.step_ptr : 0)) * a.temb_stride + ch];
+    const float add0 = v * qmain;
+    if (!SKIP && a.res_mode == 1) {
+      const size_t pixr = sample < a.B ? pix0 : 0;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int p = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hp;
+          acc[mt][nt][r] = a.res0[(pixr + p) * a.Cout + ch];
+        }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = fmaf(acc[mt][nt][r], qmain, add0);
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = add0;
+    }
+  }
+
+  struct Frag {
+    f16x8 a[2][2], b[2][2];
+  };
+  auto ldf = [&](Frag& f, const char* sArow, const char* sBt, int o0) {
+    const int o1 = o0 ^ 32;
+    f.a[0][0] = *reinterpret_cast<const f16x8*>(sArow + o0);
+    f.a[0][1] = *reinterpret_cast<const f16x8*>(sArow + o1);
+    f.a[1][0] = *reinterpret_cast<const f16x8*>(sArow + o0 + MT_OFF);
+    f.a[1][1] = *reinterpret_cast<const f16x8*>(sArow + o1 + MT_OFF);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      f.b[nt][0] = *reinterpret_cast<const f16x8*>(sBt + bofs[nt]);
+      f.b[nt][1] = *reinterpret_cast<const f16x8*>(sBt + (bofs[nt] ^ 32));
+    }
+  };
+  auto mma = [&](const Frag& f) {  // (a_l w_h, a_h w_l, a_h w_h per accumulator: the other kernels' product order)
+    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[mt][PA[q]], f.b[nt][PB[q]], acc[mt][nt], 0, 0, 0);
+  };
+
+  // ---- K loop: one barrier per unit.  At the top of unit g every DMA this wave has in flight was issued during unit
+  // g - 1 (unit g's weights; a share of the next chunk's halo), so the wait is vmcnt(0).  Behind the barrier: the weights
+  // of unit g + 1 into the other weight buffer (last read in unit g - 1), this unit's share of the NEXT chunk's halo into
+  // the other halo buffer (last read in the previous chunk), between the taps' MFMAs.
+  constexpr int HS0 = (NPH + 2) / 3, HS1 = (NPH + 1) / 3;  // halo pieces issued in a chunk's units 0 / 1 / 2: 3 2 2 or 2 2 2
+  auto unit_main = [&](int c, auto ky_tag) {
+    constexpr int KY = decltype(ky_tag)::value;
+    const int g = 3 * c + KY;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const char* sArow = sA + (c & 1) * ABYTES + KY * WR * HRW;
+    const char* sBu = sB + (g & 1) * UB;
+    const bool nxt = g + 1 < G;
+    const bool halo_nxt = c + 1 < nmain;
+    constexpr int J0 = KY == 0 ? 0 : (KY == 1 ? HS0 : HS0 + HS1);
+    constexpr int J1 = KY == 0 ? HS0 : (KY == 1 ? HS0 + HS1 : NPH);
+    Frag f0, f1;
+    ldf(f0, sArow, sBu, aofs[0]);
+    ldf(f1, sArow, sBu + TAPB, aofs[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (nxt) wdma1(g + 1, 0);
+    if (halo_nxt && J0 < J1) hdma1(c + 1, J0);
+    mma(f0);
+    __builtin_amdgcn_sched_barrier(0);
+    ldf(f0, sArow, sBu + 2 * TAPB, aofs[2]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (nxt) wdma1(g + 1, 1);
+    if (halo_nxt && J0 + 1 < J1) hdma1(c + 1, J0 + 1);
+    mma(f1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (nxt) wdma1(g + 1, 2);
+    if (halo_nxt && J0 + 2 < J1) hdma1(c + 1, J0 + 2);
+    mma(f0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+  using K2 = std::integral_constant<int, 2>;
+#pragma unroll 1
+  for (int c = 0; c < nmain; ++c) {
+    unit_main(c, K0{});
+    unit_main(c, K1{});
+    unit_main(c, K2{});
+    // SKIP: the first raw chunk goes into the other halo buffer behind the last main chunk's MFMAs (nobody reads that
+    // buffer any more: the last main chunk's predecessor is done)
+    if (SKIP && c == nmain - 1) {
+      const float rs = a.hq_skip[0] * a.hq[1];  // the 1x1 skip weights carry their own scale: q_main -> q_skip
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = acc[mt][nt] * rs;
+      scommit(rs0, nmain);
+      if (nskip > 2) sissue(rs0, 2);
+    }
+  }
+  if (SKIP) {
+    auto unit_skip = [&](f32x4 (&ra)[NIS], int k) {  // skip chunk k: halo buffer (nmain + k) & 1, `ra` holds chunk k + 1
+      const int g = 3 * nmain + k;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (g + 1 < G) wdma1(g + 1, 0);
+      Frag f;
+      ldf(f, sA + ((nmain + k) & 1) * ABYTES + WR * HRW, sB + (g & 1) * UB, aofs[1]);  // (the centre tap)
+      mma(f);
+      if (k + 1 < nskip) {
+        scommit(ra, nmain + k + 1);
+        if (k + 3 < nskip) sissue(ra, k + 3);
+      }
+    };
+#pragma unroll 1
+    for (int k = 0; k < nskip; k += 2) {
+      unit_skip(rs1, k);
+      if (k + 1 < nskip) unit_skip(rs0, k + 1);
+    }
+    if (!(hmax < HX_BIG)) atomicOr(a.range_flag, 1u);
+  }
+
+  // ---- epilogue
+  {
+    const float qinv = SKIP ? a.hq_skip[1] : a.hq[1];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = acc[mt][nt] * qinv;
+  }
+  if (sample >= a.B) return;  // (wave-uniform; no barrier follows)
+  if (a.small_check && a.range_flag) {
+    float m = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) m = hx_absmax3(acc[mt][nt][r], acc[mt][nt][r + 1], m);
+    hx_small_flag(a.range_flag, m);
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int p = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hp;
+      float* op = a.out + (pix0 + p) * a.Cout + ch0;
+      op[0] = acc[mt][0][r];
+      op[32] = acc[mt][1][r];
+    }
+  if (a.stats_out) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      float s = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[mt][nt][r];
+      s += __shfl_xor(s, 32);
+      const float mean = s / 64.f;
+      float m2 = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float d = acc[mt][nt][r] - mean;
+          m2 += d * d;
+        }
+      m2 += __shfl_xor(m2, 32);
+      if (hp == 0) store_stats(a, a.stats_out + (((size_t)sample * a.g.nparts + part) * a.Cout + ch0 + 32 * nt) * 2, mean, m2);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- host side
-static int g_hx2d_on = 1;
+// 0: off; 1: the eight-wave kernel everywhere; 2: the four-wave kernel everywhere (tools/kbench A/B); 3 (default): by
+// layer shape -- never by batch, so a row's result cannot depend on its launch; the two cuts add the same products in the
+// same order anyway.  Measured at B = 512 / 32 (tools/kbench, profiles/r04_kbench/hx2d_cuts.txt): with a fused 1x1 skip the
+// four-wave cut wins everywhere (16x16, 128 channels, 256-channel skip: 149 vs 204 us); without one the eight-wave cut
+// wins at 8x8 (28.9 vs 30.8 us; 19.4 vs 22.6 at 32 rows) and the four-wave cut at 16x16 (103.6 vs 107.2).
+static int g_hx2d_on = 3;
 void conv_hx2d_set(int v) { g_hx2d_on = v; }
+
+static size_t hx2d4_lds_bytes(const ConvArgs& a) {
+  const int npc = a.g.W == 8 ? 25 : 21;
+  return (size_t)2 * npc * 1024 + (size_t)2 * 3 * 64 * HRW;
+}
 
 static size_t hx2d_lds_bytes(const ConvArgs& a) {
   const int npc = a.g.W == 8 ? 25 : 21;
@@ -384,6 +735,10 @@ int conv_hx2d_init() {
   rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_hx2d_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_hx2d_kernel<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_hx2d_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_hx2d4_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_hx2d4_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_hx2d4_kernel<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_hx2d4_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   return rc;
 }
 
@@ -392,6 +747,17 @@ void launch_conv_hx2d(const ConvArgs& a, hipStream_t s) {
   const dim3 grid(tiles, a.Cout / 64);
   const size_t lds = hx2d_lds_bytes(a);
   const bool skip = a.res_mode == 2;
+  if (g_hx2d_on == 2 || (g_hx2d_on == 3 && (skip || a.g.W == 16))) {
+    const size_t lds4 = hx2d4_lds_bytes(a);
+    if (a.g.W == 8) {
+      if (skip) hipLaunchKernelGGL((conv_mfma_hx2d4_kernel<8, true>), grid, dim3(256), lds4, s, a, tiles);
+      else hipLaunchKernelGGL((conv_mfma_hx2d4_kernel<8, false>), grid, dim3(256), lds4, s, a, tiles);
+    } else {
+      if (skip) hipLaunchKernelGGL((conv_mfma_hx2d4_kernel<16, true>), grid, dim3(256), lds4, s, a, tiles);
+      else hipLaunchKernelGGL((conv_mfma_hx2d4_kernel<16, false>), grid, dim3(256), lds4, s, a, tiles);
+    }
+    return;
+  }
   if (a.g.W == 8) {
     if (skip) hipLaunchKernelGGL((conv_mfma_hx2d_kernel<8, true>), grid, dim3(512), lds, s, a, tiles);
     else hipLaunchKernelGGL((conv_mfma_hx2d_kernel<8, false>), grid, dim3(512), lds, s, a, tiles);

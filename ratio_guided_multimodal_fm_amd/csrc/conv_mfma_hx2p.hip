@@ -48,7 +48,9 @@ namespace rgfm {
 // launch: a unit's time is proportional to the work in it, not to the number of barriers.  tools/kbench/variants/ has them.)
 enum { HX2P_TWO_TILES = 0, HX2P_PAIRN = 1, HX2P_FOUR_WAVES = 2, HX2P_PAIRN_HALF = 3 };
 
-template <int NT, int MODE, int CFG>
+// POUT: the instantiations that can ALSO write the output in P format (ConvArgs::pout) -- separate ones, so that the block
+// costs the others nothing (in the common template it pushed the 255-register two-tile kernel into scratch)
+template <int NT, int MODE, int CFG, bool POUT = false>
 __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a, const int num_tiles) {
   constexpr bool PAIRN = CFG == HX2P_PAIRN || CFG == HX2P_PAIRN_HALF;
   constexpr bool HALF = CFG == HX2P_PAIRN_HALF;  // the packed weight blocks hold 128 channels, this workgroup takes 64 of them
@@ -771,7 +773,7 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
           pix = (unsigned)((bw * (2 * H) + 2 * rr + py) * (2 * W) + 2 * xx + px);
         }
         float* op = a.out + (size_t)(__umul24(pix, (unsigned)a.Cout) + (unsigned)(n0 + l31));
-        if (valid) {
+        if (valid && (!POUT || a.out)) {  // (out == null: a P-format-only producer, ConvArgs::pout)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) op[nt * 32] = acc[mt][nt][r];
         }
@@ -831,6 +833,67 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
   const bool full_seg = sample_ok && ((g.spt == 1) ? (nvalid - 64 * seg >= 64) : (HW == 64));  // wave-uniform
   if (full_seg) epilogue(std::true_type{});
   else epilogue(std::false_type{});
+
+  // ---------------------------------------------------------------- P format for the consumer's norm (ConvArgs::pout)
+  // 16x16 rasters only (the host checks: a tile is one whole sample, 256 pixels = the four segments of the four waves that
+  // share this wave's channels): every wave publishes its channels' (mean, M2) over its 64 pixels in LDS, combines the
+  // four segments in segment order (fp64, the consumer-side prologue's formula), finishes the group statistics with a
+  // butterfly over the group's lanes and writes S_A silu(norm(h)) split into the two fp16 planes (conv_hx2_common.h).
+  // A result does not depend on how the launch was cut: the four partials of a channel are the same numbers in every CFG.
+  if constexpr (POUT && MODE == CONV_S1) {
+    if (a.pout) {  // (kernel-uniform: every wave of every workgroup meets the two barriers)
+      __syncthreads();  // all waves are past their last fragment reads: the staging buffers are free
+      float* const sx = reinterpret_cast<float*>(smemp);  // [wave][NT][32][2]
+      float gam[NT], bet[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int c = n0 + nt * 32 + l31;
+        gam[nt] = a.pn_gamma[c], bet[nt] = a.pn_beta[c];
+        float sm = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sm += acc[mt][nt][r];
+        sm += __shfl_xor(sm, 32);
+        const float mean = sm / 64.f;
+        float m2 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float d = acc[mt][nt][r] - mean;
+            m2 += d * d;
+          }
+        m2 += __shfl_xor(m2, 32);
+        if (h == 0) {
+          float2 v;
+          v.x = mean, v.y = m2;
+          *reinterpret_cast<float2*>(sx + ((wave * NT + nt) * 32 + l31) * 2) = v;
+        }
+      }
+      __syncthreads();
+      if (full_seg) {
+        const unsigned pstride = (unsigned)a.Cout * 4u;
+        float pm = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+          for (int sg = 0; sg < 4; ++sg) {
+            const float2 v = *reinterpret_cast<const float2*>(sx + (((wave - seg + sg) * NT + nt) * 32 + l31) * 2);
+            s1 += 64.0 * (double)v.x;
+            s2 += (double)v.y + 64.0 * (double)v.x * (double)v.x;
+          }
+          float sc, sh;
+          hx_group_affine_s(s1, s2, 256.0, a.Cout >> 3, gam[nt], bet[nt], sc, sh);
+          const int c = n0 + nt * 32 + l31;
+          char* const rec0 = reinterpret_cast<char*>(a.pout) + (pix0 + (size_t)(64 * seg)) * pstride + (size_t)(c >> 4) * 64;
+          pm = fmaxf(pm, hx_p_emit(acc[0][nt], acc[1][nt], sc, sh, rec0, pstride, l31, h));
+        }
+        if (!(pm < HX_BIG)) atomicOr(a.range_flag, 1u);
+      }
+    }
+  }
 
 }
 
@@ -892,6 +955,10 @@ int conv_hx2p_init() {
   RAISEP(1, CONV_S1, HX2P_FOUR_WAVES); RAISEP(1, CONV_UP2, HX2P_FOUR_WAVES);
   RAISEP(2, CONV_S1, HX2P_FOUR_WAVES); RAISEP(2, CONV_UP2, HX2P_FOUR_WAVES);
 #undef RAISEP
+#define RAISEPP(NTV, P) rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_hx2p_kernel<NTV, CONV_S1, P, true>), \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+  RAISEPP(2, HX2P_PAIRN); RAISEPP(1, HX2P_PAIRN_HALF); RAISEPP(2, HX2P_TWO_TILES); RAISEPP(2, HX2P_FOUR_WAVES);
+#undef RAISEPP
   return rc;
 }
 
@@ -906,6 +973,15 @@ void launch_conv_hx2p(const ConvArgs& a_in, int mode, hipStream_t s) {
             cfg == HX2P_PAIRN ? a.Cout / 128 : (cfg == HX2P_PAIRN_HALF ? a.Cout / 64 : a.Cout / (32 * nt)), 1);
   const size_t lds = hx2p_lds_bytes(a, cfg);
 #define LAUNCHP(NTV, M, P) hipLaunchKernelGGL((conv_mfma_hx2p_kernel<NTV, M, P>), grid, dim3(P == HX2P_FOUR_WAVES ? 256 : 512), lds, s, a, tiles)
+  if (a.pout) {  // (the walk has checked hx2p_pout_supported: 16x16 stride-1, 64 / 128 / 256 output channels)
+#define LAUNCHPP(NTV, P) hipLaunchKernelGGL((conv_mfma_hx2p_kernel<NTV, CONV_S1, P, true>), grid, dim3(P == HX2P_FOUR_WAVES ? 256 : 512), lds, s, a, tiles)
+    if (cfg == HX2P_PAIRN) LAUNCHPP(2, HX2P_PAIRN);
+    else if (cfg == HX2P_PAIRN_HALF) LAUNCHPP(1, HX2P_PAIRN_HALF);
+    else if (cfg == HX2P_FOUR_WAVES) LAUNCHPP(2, HX2P_FOUR_WAVES);
+    else LAUNCHPP(2, HX2P_TWO_TILES);
+#undef LAUNCHPP
+    return;
+  }
 #define LAUNCHM(NTV, P)                           \
   do {                                            \
     if (mode == CONV_S1) LAUNCHP(NTV, CONV_S1, P); \

@@ -357,8 +357,11 @@ int guid_apply_init() {  // (64 KB of dynamic LDS)
          (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&guid_apply_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 }
 
-void launch_guid_apply(const GuidanceArgs& a, hipStream_t s) {
+void launch_guid_weights(const GuidanceArgs& a, hipStream_t s) {  // (needs the distances only: no velocity)
   hipLaunchKernelGGL(guid_weights_kernel, dim3((a.B + 3) / 4), dim3(256), (size_t)4 * a.N * sizeof(float), s, a);
+}
+
+void launch_guid_apply(const GuidanceArgs& a, hipStream_t s) {
   const size_t lds = (size_t)4 * 64 * 64 * sizeof(float);
   const dim3 grid((a.B + 31) / 32, (a.dx + 127) / 128 + (a.dy + 127) / 128);
   if (a.N % 32 == 0) hipLaunchKernelGGL(guid_apply_mfma_kernel<true>, grid, dim3(256), lds, s, a);

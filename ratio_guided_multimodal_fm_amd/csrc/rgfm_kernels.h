@@ -1,4 +1,4 @@
-// rgfm_kernels.h -- internal interface between the C-ABI host code (rgfm_api.cpp)
+// rgfm_kernels.h -- internal interface between the C-ABI host code (rgfm_host.h, api_*.cpp)
 // and the gfx950 kernels.  Not part of the public ABI (that is include/rgfm.h).
 //
 // HBM data layout (DESIGN.md "Data layout"):
@@ -92,6 +92,12 @@ struct ConvArgs {
   // by launch_hx_presplit) -- staged by LDS-DMA only; `zeros` = 64 zero bytes on the device (the padding records' source)
   const void* pin0;
   const void* zeros;
+  // ... and the producing side: when set, the epilogue ALSO (out != null) or ONLY (out == null) writes the output in P
+  // format for the ONE norm that consumes it (8 groups over Cout channels, parameters pn_gamma / pn_beta [Cout]):
+  // kernels whose workgroups own whole (sample, group) sets (rgfm_host.h: p_producer_ok)
+  void* pout;
+  const float* pn_gamma;
+  const float* pn_beta;
   const float* wpk;  // packed 3x3 weights  [Cout/(32NT)][Cin/16][9][32NT][16]
   const void* wpk3;  // the same weights as three bf16 planes [..][9][32NT][3][16] (conv_mfma_bx3.hip) or null
   const void* wskip3;
@@ -342,7 +348,8 @@ struct GuidanceArgs {
 };
 constexpr int RGFM_GUID_SLICES = 8;
 void launch_guid_logp(const GuidanceArgs& a, hipStream_t s);   // distances -> GuidanceArgs::dist
-void launch_guid_apply(const GuidanceArgs& a, hipStream_t s);  // weights, guided velocity, blend (+ Euler)
+void launch_guid_weights(const GuidanceArgs& a, hipStream_t s);  // distances + ratios -> importance weights (GuidanceArgs::wbuf, wsum)
+void launch_guid_apply(const GuidanceArgs& a, hipStream_t s);  // guided velocity (the [B,N] x [N,D] GEMM), blend (+ Euler)
 int guid_apply_init();                                         // (once per process: the GEMM kernel's LDS size)
 void launch_euler(float* x, const float* v, size_t n, float dt, hipStream_t s);
 void launch_step_inc(int* step, hipStream_t s);  // *step += 1

@@ -82,6 +82,7 @@ int main(int argc, char** argv) {
   conv_hx2s_init();
   conv_hx2c_init();
   conv_hx2d_init();
+  if (getenv("RGFM_HX2D")) conv_hx2d_set(atoi(getenv("RGFM_HX2D")));  // 1: eight waves, 2: four waves x two workgroups per CU
   conv_hx2c_set_all(1);
   if (getenv("RGFM_HX2Q_MIN")) conv_hx2q_set_min(atoi(getenv("RGFM_HX2Q_MIN")));
   if (getenv("RGFM_HX2Q_TPW")) conv_hx2q_set_tpw(atoi(getenv("RGFM_HX2Q_TPW")));
@@ -198,6 +199,11 @@ int main(int argc, char** argv) {
     ad.ab = nullptr, ad.pin0 = pbuf, ad.zeros = zer;
     if (!conv_hx2d_supported(ad, mode)) { printf("hx2d: unsupported shape\n"); return 1; }
   }
+  if (getenv("RGFM_KB_POUT")) {  // the producing side of the P-format hand-over: 1 = beside the fp32 map, 2 = instead of it
+    void* pob;
+    hipMalloc(&pob, (size_t)B * S * S * Cout * 4);
+    ap.pout = pob, ap.pn_gamma = dev_rand(Cout, 1.f, 31), ap.pn_beta = dev_rand(Cout, 0.3f, 32);
+  }
   if (hx2p && !conv_hx2p_supported(ap, mode)) { printf("hx2p: unsupported shape\n"); return 1; }
   if (hx2q && !conv_hx2q_supported(ap, mode)) { printf("hx2q: unsupported shape\n"); return 1; }
   if (hx2s && !conv_hx2s_supported(a, mode)) { printf("hx2s: unsupported shape\n"); return 1; }
@@ -259,6 +265,7 @@ int main(int argc, char** argv) {
   hipMemcpyToSymbol(HIP_SYMBOL(g_bx3_prof), zero, sizeof(zero));
 #endif
 #endif
+  if (getenv("RGFM_KB_POUT") && atoi(getenv("RGFM_KB_POUT")) == 2) ap.out = nullptr, ap.stats_out = nullptr;  // (timing only)
   hipEvent_t e0, e1;
   hipEventCreate(&e0), hipEventCreate(&e1);
   const int reps = getenv("REPS") ? atoi(getenv("REPS")) : 20;

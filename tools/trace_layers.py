@@ -2,7 +2,7 @@
 """Per-layer efficiency from a rocprofv3 kernel trace of bench.py.
 
 Reconstructs the conv_mfma launch sequence of one SVHN and one MNIST32 U-Net
-evaluation (same walk as csrc/rgfm_api.cpp UNetRun::run), attaches algorithmic
+evaluation (same walk as csrc/rgfm_host.h UNetRun::run), attaches algorithmic
 FLOPs to each launch, and prints achieved TFLOP/s per layer for one main-loop
 step (B rows) of the trace.  Usage: trace_layers.py <kernel_trace.csv> [B]"""
 import csv
