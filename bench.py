@@ -352,7 +352,7 @@ def main():
             # committed under profiles/ with the hash of the kernel sources it was taken with; it is reported only
             # while those sources are unchanged, and the line names the file and its sha256.
             traffic, traffic_src = None, None
-            tpath = os.path.join(ROOT, "profiles", f"r03_conv_traffic_{conv_mode}.json")
+            tpath = os.path.join(ROOT, "profiles", f"r04_conv_traffic_{conv_mode}.json")
             if os.path.exists(tpath) and args.batch_per_gpu == 512:
                 import hashlib
                 with open(tpath, "rb") as f:
@@ -376,7 +376,7 @@ def main():
                           "launches overlap; sum_launch_ms double-counts that time; RGFM_OVERLAP=0 serialises)",
                 "kernel_time_share": conv_ms * 1e-3 / elapsed,
             }
-            lt = os.path.join(ROOT, "profiles", "r03_bench_layers_serial.txt")
+            lt = os.path.join(ROOT, "profiles", "r04_bench_layers_serial.txt")
             if os.path.exists(lt) and conv_mode == "hx2":
                 # (static pointer, not a live number) rocprofv3 per-layer table of one main-loop step with every layer's
                 # own roofline max(MFMA ceiling, HBM copy rate): a third of the step is memory-bound, DESIGN.md 4
@@ -394,6 +394,7 @@ def main():
             bnd = args.batch_per_gpu * args.mc * (1024.0 + 3072.0)
             arith_classes = {"guid_logp": ("valu_f32", 3.0 * bnd, PEAK_FP32_MFMA_TFLOPS),  # (packed fp32 VALU peak = fp32 MFMA peak)
                              "guid_apply": ("mfma_f32", 2.0 * bnd, PEAK_FP32_MFMA_TFLOPS)}
+            guided_steps = hbm_classes.get("guid_logp", (0, 0, 0, 0))[2]  # one "guid_logp" scope (distances + weights) per guided step
             for name, (busy, tot, nl, by) in hbm_classes.items():
                 if nl > 0 and tot > 0:
                     gbs = by / (tot * 1e-3) / 1e9
@@ -402,8 +403,11 @@ def main():
                                 "frac_measured_copy": (gbs / ceilings["hbm_copy_gbs"]) if ceilings else None}
                     if name in arith_classes:
                         bound, fl, peak = arith_classes[name]
-                        tf = fl / (1e-3 * tot / nl) / 1e12
-                        hk[name].update({"bound": bound, "algorithmic_tflops": tf, "peak_tflops": peak, "frac_arith": tf / peak})
+                        # per guided STEP: the decoupled loop launches guid_apply once per modality (two scopes a step)
+                        per_step_ms = tot / (guided_steps if guided_steps else nl)
+                        tf = fl / (1e-3 * per_step_ms) / 1e12
+                        hk[name].update({"bound": bound, "per_step_us": 1e3 * per_step_ms, "algorithmic_tflops": tf,
+                                         "peak_tflops": peak, "frac_arith": tf / peak})
                     else:
                         hk[name]["bound"] = "hbm"
             if hk:

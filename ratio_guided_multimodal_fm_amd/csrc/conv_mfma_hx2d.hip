@@ -363,6 +363,9 @@ __global__ __launch_bounds__(512, 1) void conv_mfma_hx2d_kernel(const ConvArgs a
 // tile x 64 channels, and the weights are double-buffered per UNIT of three taps (12 KB) instead of per chunk, so that a
 // workgroup needs <= 80 KB and TWO share a CU: the two waves of a SIMD belong to different workgroups with their own
 // barriers, and one's barrier / DMA-issue gaps fall under the other's MFMAs.
+// (Tried on this cut and dropped, profiles/r04_kbench/hx2d4_triple_weight_buffers.txt: THREE weight buffers at 16x16 with the
+// weights requested two units ahead and a counted vmcnt that leaves the previous unit's requests in flight -- 105.7 vs
+// 103.6 us at 128 channels, 33.1 vs 32.3 at 64, slower at 32 rows: the wait for the DMA is not what the unit's time is made of.)
 template <int W, bool SKIP>
 __global__ __launch_bounds__(256, 2) void conv_mfma_hx2d4_kernel(const ConvArgs a, const int num_tiles) {
   constexpr int SPT = W == 8 ? 4 : 1, H = W, WR = W + 2, HR = H + 2;

@@ -698,7 +698,11 @@ struct UNetRun {
     // of h1, whose only reader is conv2 through norm2 + SiLU (unet_flexible.py:79-81) -- conv1 writes silu(norm2(h1))
     // already split, conv2 stages it by LDS-DMA.  The buffer is carved whenever the SHAPE allows it (dry and real walks
     // alike); whether the two launches take the hand-over is decided from the kernels they are dispatched to.
-    if ((a.S == 8 || a.S == 16) && r.cout % 64 == 0) {
+    // Where it pays (tools/kbench, profiles/r04_kbench/p_producer_overhead.txt + hx2d_cuts.txt, B = 512): writing the P
+    // format costs the producer 2.2 us at 8x8 (of 36), 3.5 us at 16x16 / 64 channels, 6.5 us at 16x16 / 128 channels (its
+    // epilogue is vector-ALU-bound: SiLU + split of every output); the consumer gains 6.7 / 5.5 - 6.5 / 3.6 - 4.4 us.  So:
+    // the 8x8 level and 64-channel 16x16 layers; 128-channel 16x16 layers keep the fp32 hand-over.
+    if ((a.S == 8 || (a.S == 16 && r.cout == 64)) && r.cout % 64 == 0) {
       h1.p = ws->f((size_t)B * a.S * a.S * r.cout);
       if (!dry && pend.valid && pend.c.out == h1.data && r.c1.hx_ok && r.c2.hx_ok && (!r.has_skip || r.sk.hx_ok)) {
         pend.c.pout = h1.p, pend.c.pn_gamma = h->params + r.n2w, pend.c.pn_beta = h->params + r.n2b;
@@ -831,7 +835,7 @@ inline int guidance_launch(const float* x, const float* y, float* vx, float* vy,
                     float* weights_out, float* xs, float* ys, float dt, hipStream_t s, const float* sched = nullptr,
                     const int* step_ptr = nullptr, int phase = 0) {
   // phase 0: the whole block; 1: distances + importance weights only -- they need the step's (x_t, y_t) and the MC set,
-  // not the velocities, so the paired loop runs them while the slower net is still evaluating; 2: the rest (needs v)
+  // not the velocities; 2: the rest (needs v)
   if (dx % 4 || dy % 4) return fail(RGFM_EINVAL, "flattened image sizes must be multiples of 4");
   if ((size_t)4 * N * sizeof(float) > 64 * 1024) return fail(RGFM_EINVAL, "n_mc too large (max 4096)");
   // Python-double scalar arithmetic of the reference (sample_mnist_svhn.py:115,127,135,159,170),
@@ -851,7 +855,7 @@ inline int guidance_launch(const float* x, const float* y, float* vx, float* vy,
   // algorithmic bytes.  logp: rows of x, y and the MC set in, the sliced fp64 distances out.  apply: the
   // distances, x, y, v and the MC set in, the new state (or velocity) out.
   const double D = (double)dx + dy, dist_b = 8.0 * (a.nsx + a.nsy) * (double)B * N;
-  if (phase != 2) {  // (timer class "guid_logp": the distances AND the importance weights made of them)
+  if (phase < 2) {  // (timer class "guid_logp": the distances AND the importance weights made of them)
     ProfScope p(RGFM_KCLASS_GUID_LOGP, 4.0 * (B + N) * D + dist_b, s);
     launch_guid_logp(a, s);
     launch_guid_weights(a, s);
@@ -954,6 +958,10 @@ int pair_loop(EvalX&& eval_x, EvalY&& eval_y, float* x_inout, float* y_inout, co
       }
     }
   } exit_guard{ds, s, caller, &exec};
+  // (Measured and rejected in round 4, profiles/r04_ab_decoupled_loop.txt: the loop WITHOUT the per-step join -- each
+  // modality a chain net -> its half of the guided update on its own stream, coupled only through two events per step
+  // around the importance weights, the x net up to one evaluation ahead -- is bit-identical and 0.5 - 0.9 % SLOWER
+  // (469 - 471 vs 473 paired images/s, same box, alternating): the join costs nothing the chains could use.)
   for (int i = 0; i < ns; ++i) {
     const double t = (double)(step_begin + i) * dtd;
     const bool guided = n_mc > 0 && t > 1e-3;  // `t > eps` test of the reference (:124)

@@ -15,6 +15,120 @@ namespace rgfm {
 // halves take alternate pixels.  The zero-padded halo is staged as one float4 (<= 4 input channels)
 // per pixel, so a tap is a single aligned broadcast ds_read_b128: 9 LDS reads + 9*CIN FMAs per
 // pixel (f32 VALU and LDS issue share the SIMD: the instruction count is the bound).
+// conv_in_pk_kernel (C0 % 64 == 0, no epilogue activation: the U-Nets' input convs): TWO output channels per lane (c, c + 32) as
+// one packed accumulator -- v_pk_fma_f32 with the tap value in both halves and the lane's weight pair -- and the two wave halves
+// on alternate pixels, so a wave instruction covers two pixels x 64 channels.  The kernel is bound by its instruction count
+// (9 LDS reads + 9 CIN multiply-adds per pixel and lane in the one-channel form): this halves both.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_in_pk_kernel(const ConvInArgs a) {
+  typedef float ci_f32x2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const TileGeom g = a.g;
+  const int W = g.W, H = g.H, HW = g.HW;
+  int b0, row0;
+  if (g.spt == 1) {
+    b0 = blockIdx.x / g.tps;
+    row0 = (blockIdx.x - b0 * g.tps) * g.th;
+  } else {
+    b0 = blockIdx.x * g.spt;
+    row0 = 0;
+  }
+  const int HR = g.th + 2, WR = W + 2, per = HR * WR;
+  int rows_valid = H - row0;
+  if (rows_valid > g.th) rows_valid = g.th;
+  const int nvalid = rows_valid * W;
+  for (int it = tid; it < g.spt * per; it += 256) {
+    const int s = it / per, rem = it - s * per;
+    const int hy = rem / WR, hx = rem - hy * WR;
+    const int y = row0 + hy - 1, x = hx - 1, b = b0 + s;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (y >= 0 && y < H && x >= 0 && x < W && b < a.B) {
+      const float* p = a.x + ((size_t)b * CIN * H + y) * W + x;
+      v.x = p[0];
+      if (CIN > 1) v.y = p[(size_t)HW];
+      if (CIN > 2) v.z = p[(size_t)2 * HW];
+    }
+    *reinterpret_cast<f32x4*>(smem + 4 * it) = v;
+  }
+  __syncthreads();
+
+  const int bw = (g.spt == 1) ? b0 : b0 + wave;
+  const bool sample_ok = bw < a.B;
+  const int sidx = (g.spt == 1) ? 0 : wave;
+  int nw;
+  if (g.spt == 1) {
+    nw = nvalid - 64 * wave;
+    nw = nw < 0 ? 0 : (nw > 64 ? 64 : nw);
+  } else {
+    nw = sample_ok ? HW : 0;
+  }
+  const int q0 = (g.spt == 1) ? 64 * wave : 0;
+  const size_t pix0 = (g.spt == 1) ? (size_t)b0 * HW + (size_t)row0 * W + q0 : (size_t)bw * HW;
+  const int part = (g.spt == 1) ? (blockIdx.x - b0 * g.tps) * 4 + wave : 0;
+  const int hh = lane >> 5;
+  for (int cg = 0; cg < a.C0 / 64; ++cg) {
+    const int c = cg * 64 + (lane & 31);  // this lane's channels: c and c + 32
+    ci_f32x2 wr[CIN * 9];
+#pragma unroll
+    for (int i = 0; i < CIN * 9; ++i) wr[i] = ci_f32x2{a.w[(size_t)c * CIN * 9 + i], a.w[(size_t)(c + 32) * CIN * 9 + i]};
+    const ci_f32x2 bias = {a.bias[c], a.bias[c + 32]};
+    ci_f32x2 sum = {0.f, 0.f}, sq = {0.f, 0.f}, pivot = {0.f, 0.f};
+    float vmx = 0.f;
+    int r = (q0 + hh) / W, x = (q0 + hh) - r * W;
+#pragma unroll 2
+    for (int k = hh; k < nw; k += 2) {
+      const float* base = smem + 4 * (sidx * per + r * WR + x);
+      ci_f32x2 acc = bias;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(base + 4 * (ky * WR + kx));
+          acc = __builtin_elementwise_fma(ci_f32x2{t.x, t.x}, wr[ky * 3 + kx], acc);
+          if (CIN > 1) acc = __builtin_elementwise_fma(ci_f32x2{t.y, t.y}, wr[9 + ky * 3 + kx], acc);
+          if (CIN > 2) acc = __builtin_elementwise_fma(ci_f32x2{t.z, t.z}, wr[18 + ky * 3 + kx], acc);
+        }
+      float* op = a.out + (pix0 + k) * a.C0 + c;
+      op[0] = acc.x, op[32] = acc.y;
+      vmx = fmaxf(vmx, fmaxf(fabsf(acc.x), fabsf(acc.y)));
+      if (k == hh) pivot = acc;
+      const ci_f32x2 d = acc - pivot;
+      sum += d;
+      sq = __builtin_elementwise_fma(d, d, sq);
+      x += 2;
+      if (x >= W) x -= W, ++r;
+    }
+    if (a.small_check && a.range_flag) {  // (ConvArgs::small_check; wave-uniform)
+      float m = vmx;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      if (m > 0.f && m < HX_SMALL && lane == 0) atomicOr(a.range_flag, 2u);
+    }
+    if (a.stats_out && sample_ok && nw > 0) {
+      const float nme = (float)((nw - hh + 1) / 2);  // pixels this lane saw
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float dm = nme > 0.f ? sum[e] / nme : 0.f;
+        float mean = pivot[e] + dm;
+        float m2 = sq[e] - nme * dm * dm;
+        m2 = m2 < 0.f ? 0.f : m2;
+        // Chan-combine the two halves (disjoint pixel sets of the same channel)
+        const float no = __shfl_xor(nme, 32), mo = __shfl_xor(mean, 32), m2o = __shfl_xor(m2, 32);
+        const float nt = nme + no;
+        const float dl = mo - mean;
+        m2 = m2 + m2o + dl * dl * nme * no / nt;
+        mean = mean + dl * no / nt;
+        if (hh == 0) {
+          float2 st;
+          st.x = mean, st.y = m2;
+          *reinterpret_cast<float2*>(a.stats_out + (((size_t)bw * g.nparts + part) * a.C0 + c + 32 * e) * 2) = st;
+        }
+      }
+    }
+  }
+}
+
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_in_kernel(const ConvInArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -131,6 +245,11 @@ void launch_conv_in(const ConvInArgs& a, int cin, hipStream_t s) {
   const int per = (a.g.th + 2) * (a.g.W + 2);
   dim3 grid(geom_num_tiles(a.g, a.B));
   const size_t lds4 = (size_t)a.g.spt * per * 4 * sizeof(float);
+  if (a.C0 % 64 == 0 && !a.ep_scale) {  // (the U-Nets' 64-channel input convs: two channels per lane)
+    if (cin == 1) hipLaunchKernelGGL(conv_in_pk_kernel<1>, grid, dim3(256), lds4, s, a);
+    else hipLaunchKernelGGL(conv_in_pk_kernel<3>, grid, dim3(256), lds4, s, a);
+    return;
+  }
   if (cin == 1) hipLaunchKernelGGL(conv_in_kernel<1>, grid, dim3(256), lds4, s, a);
   else hipLaunchKernelGGL(conv_in_kernel<3>, grid, dim3(256), lds4, s, a);
 }
@@ -241,9 +360,15 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const ConvOutArgs a) {
       }
   };
 
-  float acc[CIMG];
+  // Two partial sums per output channel (even / odd input channels of every chunk): the multiply-adds of a tap are
+  // v_pk_fma_f32 -- two per instruction, the scalar weight pair as one SGPR-pair operand.  This kernel is VALU-bound
+  // (CIMG = 3: 432 multiply-adds per pixel and chunk against 36 LDS reads), and unlike the conv kernels it has no MFMAs
+  // of its own for the packed form to get in the way of (its workgroups do not share a SIMD with a conv's: those take
+  // all of a CU's registers).
+  typedef float co_f32x2 __attribute__((ext_vector_type(2)));
+  co_f32x2 acc[CIMG];
 #pragma unroll
-  for (int co = 0; co < CIMG; ++co) acc[co] = 0.f;
+  for (int co = 0; co < CIMG; ++co) acc[co] = co_f32x2{0.f, 0.f};
 
   const int nch = a.Cin / KC;
   issue(0);
@@ -256,11 +381,11 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const ConvOutArgs a) {
     for (int tap = 0; tap < 9; ++tap) {
       const int ky = tap / 3, kx = tap - 3 * ky;
       const float* ap = smem + abase + (ky * WR + kx) * LDP;
-      float v[KC];
+      co_f32x2 v[KC / 2];
 #pragma unroll
       for (int j = 0; j < KC / 4; ++j) {
         const f32x4 t = *reinterpret_cast<const f32x4*>(ap + 4 * j);
-        v[4 * j] = t.x, v[4 * j + 1] = t.y, v[4 * j + 2] = t.z, v[4 * j + 3] = t.w;
+        v[2 * j] = co_f32x2{t.x, t.y}, v[2 * j + 1] = co_f32x2{t.z, t.w};
       }
       // weights re-laid out as [chunk][tap][co][16] (launch_pack_conv_out): the 16 * CIMG scalars of a tap are
       // contiguous, so they arrive as wide scalar loads instead of 16 * CIMG strided s_load_dword
@@ -268,7 +393,8 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const ConvOutArgs a) {
 #pragma unroll
       for (int co = 0; co < CIMG; ++co)
 #pragma unroll
-        for (int kk = 0; kk < KC; ++kk) acc[co] += v[kk] * wt[co * KC + kk];
+        for (int kk = 0; kk < KC / 2; ++kk)
+          acc[co] = __builtin_elementwise_fma(v[kk], *reinterpret_cast<const co_f32x2*>(wt + co * KC + 2 * kk), acc[co]);
     }
   }
   if (!valid) return;
@@ -276,7 +402,7 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const ConvOutArgs a) {
   const int pixl = (g.spt == 1) ? row0 * W + p : (p & 63);
 #pragma unroll
   for (int co = 0; co < CIMG; ++co) {
-    const float v = acc[co] + a.bias[co];
+    const float v = (acc[co].x + acc[co].y) + a.bias[co];
     const size_t idx = ((size_t)b * CIMG + co) * HW + pixl;
     if (a.v_out) a.v_out[idx] = v;
     if (a.x_state) a.x_state[idx] = __fadd_rn(a.x_state[idx], __fmul_rn(v, a.dt));
