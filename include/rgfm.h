@@ -107,6 +107,10 @@ int rgfm_unet_set_trace(rgfm_unet* h, int enable);
 int rgfm_unet_time_embedding(rgfm_unet* h, const float* t_dev, int t_count, float* emb_out, void* ws,
                              size_t ws_bytes, rgfm_stream_t stream);
 int rgfm_unet_num_activations(const rgfm_unet* h, int* n);
+/* Debug / test hook: how many ResBlocks of the handle's LATEST network walk handed conv1's output to conv2 in the
+ * pre-normalised pre-split "P format" (conv_mfma_hx2d.hip) instead of as an fp32 map.  Lets a
+ * test see that the hand-over is really taken (its results are the fp32 hand-over's to the last bit or two). */
+int rgfm_unet_p_handovers(const rgfm_unet* h, int* blocks);
 int rgfm_unet_activation_shape(const rgfm_unet* h, int index, int* channels, int* height, int* width);
 int rgfm_unet_read_activation(rgfm_unet* h, int index, int batch, const void* ws, float* out_dev,
                               rgfm_stream_t stream);

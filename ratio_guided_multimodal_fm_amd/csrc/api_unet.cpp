@@ -195,6 +195,12 @@ void act_table(const rgfm_unet* h, std::vector<std::pair<int, int>>& t) {
 }
 }  // namespace
 
+extern "C" int rgfm_unet_p_handovers(const rgfm_unet* h, int* blocks) {
+  if (!h || !blocks) return fail(RGFM_EINVAL, "null argument");
+  *blocks = h->p_handovers;
+  return RGFM_OK;
+}
+
 extern "C" int rgfm_unet_num_activations(const rgfm_unet* h, int* n) {
   if (!h || !n) return fail(RGFM_EINVAL, "null argument");
   std::vector<std::pair<int, int>> t;

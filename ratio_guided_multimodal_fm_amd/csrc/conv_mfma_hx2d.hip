@@ -355,6 +355,13 @@ __global__ __launch_bounds__(512, 1) void conv_mfma_hx2d_kernel(const ConvArgs a
   }
 }
 
+// (Measured and rejected, round 4 -- tools/experiments/conv_mfma_hx2d16.hip, profiles/r04_kbench/hx2d_mfma_16x16x32.txt: the
+// eight-wave kernel re-cut for v_mfma_f32_16x16x32_f16.  A register-only loop of that shape sustains 1.17 x the FLOP/s of the
+// 32x32x16 loop on this part (mfma_shapes.txt: 1982 vs 1694 TFLOP/s, a higher clock at equal cycles), but the conv is not a
+// bare MFMA loop: with K = 32 = the two planes of a chunk as one operand and a_h w_h of two taps paired by
+// v_permlane32_swap (no extra LDS reads, same results to rounding) the chunk needs 112 instructions + 24 swaps instead of
+// 54, and the launch takes 31.9 vs 28.9 us at 512 rows, 25.8 vs 19.5 at 32.)
+
 // ---------------------------------------------------------------- four waves, two workgroups per CU
 // conv_mfma_hx2d4_kernel: the same conv cut for the LDS.  The eight-wave kernel above reads 1 KB of fragments per MFMA (a
 // wave tile of 64 pixels x 32 channels: four A and two B reads per six MFMAs) -- with the DMA writes the LDS is busy ~70 % of a
@@ -365,7 +372,9 @@ __global__ __launch_bounds__(512, 1) void conv_mfma_hx2d_kernel(const ConvArgs a
 // barriers, and one's barrier / DMA-issue gaps fall under the other's MFMAs.
 // (Tried on this cut and dropped, profiles/r04_kbench/hx2d4_triple_weight_buffers.txt: THREE weight buffers at 16x16 with the
 // weights requested two units ahead and a counted vmcnt that leaves the previous unit's requests in flight -- 105.7 vs
-// 103.6 us at 128 channels, 33.1 vs 32.3 at 64, slower at 32 rows: the wait for the DMA is not what the unit's time is made of.)
+// 103.6 us at 128 channels, 33.1 vs 32.3 at 64, slower at 32 rows: the wait for the DMA is not what the unit's time is made of.
+// Nor is the LDS round trip behind the barrier: a unit's LAST tap multiplied behind the NEXT unit's barrier, from fragments
+// kept in registers (same summation order), made it 110.6 vs 103.6 / 34.7 vs 32.3 us -- hx2d4_deferred_last_tap.txt.)
 template <int W, bool SKIP>
 __global__ __launch_bounds__(256, 2) void conv_mfma_hx2d4_kernel(const ConvArgs a, const int num_tiles) {
   constexpr int SPT = W == 8 ? 4 : 1, H = W, WR = W + 2, HR = H + 2;

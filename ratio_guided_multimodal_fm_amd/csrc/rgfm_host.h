@@ -391,6 +391,7 @@ struct rgfm_unet {
   std::vector<ConvW> down, up;
   int final_ch = 0;
   bool trace = false;
+  int p_handovers = 0;  // ResBlocks of the latest walk whose conv1 -> conv2 hand-over took the P format (rgfm_unet_p_handovers)
   struct Act {
     float* data;
     int C, S;
@@ -674,6 +675,7 @@ struct UNetRun {
       cp.pin0 = a.p, cp.zeros = ds ? ds->zeros : nullptr;
       if (pend.valid && pend.c.pout == a.p && conv_hx2d_supported(cp, mode)) {
         c = cp, p_in = true;
+        h->p_handovers += 1;
         if (!h->trace) pend.c.out = nullptr, pend.c.stats_out = nullptr;  // (nothing else reads the fp32 map)
       } else if (pend.valid && pend.c.pout == a.p) {
         pend.c.pout = nullptr;
@@ -723,6 +725,7 @@ struct UNetRun {
     const rgfm_unet_desc& d = h->d;
     ModeScope mode_scope(h->conv_mode);
     if (!dry && h->trace) h->acts.clear();
+    if (!dry) h->p_handovers = 0;
     int S = d.img_size;
     Tensor cur = new_tensor(h->mc, S);
     if (!dry) {

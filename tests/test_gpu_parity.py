@@ -74,7 +74,7 @@ def test_unet_ragged_batches(dev, tag, B):
 
 
 @pytest.mark.parametrize("tag", ["g24", "g16", "g40"])
-@pytest.mark.parametrize("env", [{}, {"RGFM_CONV": "bx3"}, {"RGFM_CONV": "f32"}, {"RGFM_GN": "table"}])
+@pytest.mark.parametrize("env", [{}, {"RGFM_CONV": "bx3"}, {"RGFM_CONV": "f32"}, {"RGFM_GN": "table"}, {"RGFM_HX2D": "0"}])
 def test_generic_flexible_unets(dev, tag, env, monkeypatch):
     """FlexibleUNet shapes outside the presets -- 24x24 (three tiles per sample: tile pairs straddle samples, 12
     statistics parts), 16x16 with four levels down to 2x2 maps and three blocks per level, 40x40 (tiles of 6 rows,
@@ -413,7 +413,9 @@ def test_full_size_arithmetic_modes_agree(dev, monkeypatch):
 
 @pytest.mark.parametrize("env", [{"RGFM_CONV": "f32"}, {"RGFM_CONV": "bx3"}, {"RGFM_CONV": "bx3", "RGFM_GN": "table"},
                                  {"RGFM_GN": "table"}, {"RGFM_GN": "table", "RGFM_FUSE_FIN": "0"},
-                                 {"RGFM_CONV": "f32", "RGFM_FUSE_FIN": "0"}])
+                                 {"RGFM_CONV": "f32", "RGFM_FUSE_FIN": "0"},
+                                 # the P-format hand-over conv1 -> conv2 (conv_mfma_hx2d.hip): off, and each of its two cuts everywhere
+                                 {"RGFM_HX2D": "0"}, {"RGFM_HX2D": "1"}, {"RGFM_HX2D": "2"}])
 @pytest.mark.parametrize("tag,B", [("svhn", 5), ("mnist32", 3)])
 def test_conv_variants_keep_parity(dev, env, tag, B, monkeypatch):
     """The alternative conv arithmetic (RGFM_CONV=bx3: three exact bf16 planes, the fp32-range fallback of the
@@ -703,6 +705,38 @@ def test_guidance_late_time_concentrated_weights(dev):
         dvx, dvy = maxdiff(gvx.cpu().numpy(), ovx), maxdiff(gvy.cpu().numpy(), ovy)
         print(f"t={t} gamma={gamma}: |dv| {dvx:.2e} {dvy:.2e}  bound {bound:.2e}  |v| {float(np.abs(ovy).max()):.1f}")
         assert dvx < bound and dvy < bound, (t, dvx, dvy, bound)
+
+
+@pytest.mark.parametrize("tag", ["mnist32", "svhn"])
+def test_p_format_hand_over_against_the_fp32_hand_over(dev, tag, monkeypatch):
+    """conv1 -> conv2 inside a ResBlock at the 16x16 / 8x8 levels: with the P-format hand-over (conv1's epilogue writes
+    silu(norm2(h)) as the two fp16 planes, conv2 stages them by LDS-DMA: conv_mfma_hx2d.hip) and without it
+    (RGFM_HX2D=0: fp32 map + statistics, normalised on conv2's load path) the nets must agree far inside the per-evaluation
+    tolerance -- the two forms round the norm's statistics differently (~1e-7) and nothing else -- and both must match the
+    oracle; the eight-wave and four-wave cuts of the consumer are bit-identical."""
+    m = make_module(tag, dev)
+    desc, blob = oracle_net(tag)
+    B = 37
+    x = torch.randn(B, *SHAPES[tag], generator=torch.Generator().manual_seed(9))
+    t = torch.rand(B, generator=torch.Generator().manual_seed(10))
+    import ctypes
+    outs, taken = {}, {}
+    for v in ("3", "0", "1", "2"):
+        monkeypatch.setenv("RGFM_HX2D", v)
+        outs[v] = m(x.to(dev), t.to(dev))
+        n = ctypes.c_int()
+        _lib.check(_lib.lib().rgfm_unet_p_handovers(m._engine.handle(dev), ctypes.byref(n)))
+        taken[v] = n.value
+    monkeypatch.delenv("RGFM_HX2D")
+    # the hand-over is really taken: every ResBlock of the 8x8 level (svhn: 2 + 2 + 3) / of the 64-channel 16x16 level
+    # (mnist32: 2 + 2 + 3), and none with the switch off
+    assert taken["0"] == 0 and taken["3"] == taken["1"] == taken["2"] == 7, taken
+    assert torch.equal(outs["1"], outs["2"]) and torch.equal(outs["3"], outs["1"])
+    d = float((outs["3"] - outs["0"]).abs().max())
+    assert d < 2e-6, d  # (the same arithmetic up to the rounding of the norm's statistics -- usually to the last bit)
+    idx = [0, 1, 17, 35, 36]
+    ro = O.unet_forward(desc, blob, x.numpy()[idx], t.numpy()[idx])
+    assert maxdiff(outs["3"].cpu().numpy()[idx], ro) < TOL_EVAL and maxdiff(outs["0"].cpu().numpy()[idx], ro) < TOL_EVAL
 
 
 def test_same_module_for_both_modalities(dev):
