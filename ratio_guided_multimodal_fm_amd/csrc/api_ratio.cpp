@@ -19,6 +19,8 @@ struct rgfm_ratio {
   size_t n_params = 0, n_packed = 0, n_bn = 0;
   struct Conv {
     size_t wt_pk = 0;  // packed transposed weights (offset into gradw), convs after the first
+    ConvW wt_h;        // the same transposed weights as two scaled fp16 planes (offsets into packedh / hq): the reverse pass
+                       // inside the gradient-guided sampler runs on the U-Nets' default arithmetic (round 4)
     ConvW w;
     size_t nw = 0, nb = 0;                 // GroupNorm weight/bias (mnist28) or BatchNorm w/b
     size_t rm = 0, rv = 0;                 // BatchNorm running stats
@@ -62,6 +64,10 @@ size_t plan_ratio(const rgfm_ratio_desc& d, rgfm_ratio* h) {
       if (i > 0) cv.w.w_pk = pk.take((size_t)chans[i] * ci * 9);
       if (i > 0) cv.wt_pk = gw.take((size_t)chans[i] * ci * 9);
       if (i > 0 && h) cv.w.w_hx2 = h->n_packedh, h->n_packedh += (size_t)chans[i] * ci * 9 * 2, cv.w.hq = h->n_hq++;
+      if (i > 0 && h) {
+        cv.wt_h.cin = chans[i], cv.wt_h.cout = ci, cv.wt_h.taps = 9;
+        cv.wt_h.w_hx2 = h->n_packedh, h->n_packedh += (size_t)chans[i] * ci * 9 * 2, cv.wt_h.hq = h->n_hq++;
+      }
       cv.nw = c.take(chans[i]);
       cv.nb = c.take(chans[i]);
       if (batchnorm) {
@@ -262,6 +268,8 @@ extern "C" int rgfm_ratio_create(const rgfm_ratio_desc* desc, const float* param
     // gradient path (rgfm_ratio_grad_log_ratio): dL/d(in) of a 3x3 conv is the conv of dL/d(out) with the weights
     // transposed and the taps flipped; of a Linear, the Linear with W^T
     if (hipMalloc(&h->gradw, (h->n_gradw + 4) * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(gradw)");
+    if (hipMalloc(&h->packedh, (h->n_packedh + 8) * sizeof(unsigned short)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(packedh)");
+    if (hipMalloc(&h->hq, ((size_t)h->n_hq * 4 + 4) * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(hq)");
     float* tmp = nullptr;
     if (hipMalloc(&tmp, (size_t)256 * 256 * 9 * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(tmp)");
     for (const auto* e : {&h->ex, &h->ey}) {
@@ -269,6 +277,7 @@ extern "C" int rgfm_ratio_create(const rgfm_ratio_desc* desc, const float* param
         const auto& cv = e->convs[i];
         launch_conv_weight_transpose(h->params + cv.w.w_raw, tmp, cv.w.cout, cv.w.cin, s);
         launch_pack_conv(tmp, h->gradw + cv.wt_pk, cv.w.cin, cv.w.cout, 9, nt32_of(cv.w.cin), s);
+        launch_pack_conv_hx2(tmp, h->packedh + cv.wt_h.w_hx2, h->hq + 4 * cv.wt_h.hq, cv.w.cin, cv.w.cout, 9, CONV_S1, s);
       }
       launch_transpose2d(h->params + e->fcw, h->gradw + e->fcw_t, desc->feature_dim, e->fc_in, s);
     }
@@ -279,14 +288,13 @@ extern "C" int rgfm_ratio_create(const rgfm_ratio_desc* desc, const float* param
       return bail(RGFM_EHIP, "building the transposed weights failed");
     }
     (void)hipFree(tmp);
-    if (hipMalloc(&h->packedh, (h->n_packedh + 8) * sizeof(unsigned short)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(packedh)");
-    if (hipMalloc(&h->hq, ((size_t)h->n_hq * 4 + 4) * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(hq)");
     std::vector<ConvW*> all;
     for (auto* e : {&h->ex, &h->ey})
       for (size_t i = 1; i < e->convs.size(); ++i) {
         ConvW& w = e->convs[i].w;
         launch_pack_conv_hx2(h->params + w.w_raw, h->packedh + w.w_hx2, h->hq + 4 * w.hq, w.cout, w.cin, 9, CONV_S1, s);
         all.push_back(&w);
+        all.push_back(&e->convs[i].wt_h);
       }
     if (read_hx_flags(h->hq, h->n_hq, all, s) != RGFM_OK) return bail(RGFM_EHIP, "reading the fp16 scale records failed");
   }
@@ -349,6 +357,8 @@ struct RatioGradRun {
   // caller's ModeScope) and raise ITS flag, so that the sampler's range guard and fallback cover them.
   unsigned* flag = nullptr;
   float* ab1 = nullptr;  // [n][256][2] identity scale/shift: "SiLU on load"
+  unsigned* amax = nullptr;  // one word per reverse conv: bits of max |gradient| of its input (ConvArgs::in_amax); zeroed per call
+  int amax_used = 0;
 
   struct Kept {
     float* z;
@@ -478,12 +488,15 @@ struct RatioGradRun {
       if (i != (int)kept.size() - 1) mode = k.pooled ? 1 : 0;
       else mode = k.pooled ? 3 : 2;  // (SVHN encoder: a max-pool sits between the last conv and the average pool)
       float* gz = ws->f((size_t)n * k.S * k.S * k.C);
+      unsigned* am = nullptr;
       if (!dry) {
         if (k.ab) {  // GroupNorm encoder: SiLU' (and the max-pool routing) at u = a z + b, then the norm's backward in place
           launch_grad_act_gn(g, k.z, k.ab, gz, n, k.S, k.C, mode, s);
           launch_gn_bwd(gz, k.z, h->params + cv.nw, k.mr, n, k.S * k.S, k.C, 8, s);
         } else {
-          launch_grad_act(g, k.z, h->bn + cv.bn_scale, gz, n, k.S, k.C, mode, s);
+          // (inside the sampler the next conv runs on the two-plane arithmetic: it needs the tensor's magnitude)
+          am = (flag && i > 0 && amax && g_modes.conv == CONV_ARITH_HX2 && g_modes.rev_hx2 && cv.wt_h.hx_ok) ? amax + amax_used++ : nullptr;
+          launch_grad_act(g, k.z, h->bn + cv.bn_scale, gz, n, k.S, k.C, mode, s, am);
         }
       }
       if (i == 0) {
@@ -497,7 +510,18 @@ struct RatioGradRun {
           c.out = gin, c.stats_out = nullptr, c.B = n, c.Cout = cv.w.cin;
           c.g = make_geom(k.S, k.S);
           c.halo_px = c.g.spt * (c.g.th + 2) * (c.g.W + 2);
-          launch_conv_mfma(c, CONV_S1, s);
+          // Inside the gradient-guided sampler (flag set): the data gradient on the two-plane fp16 arithmetic.  Gradients
+          // are 1e-3 ... 1e-6 in magnitude -- below the raw staging window -- so the conv stages them x 2^-e for the
+          // tensor's measured maximum f 2^e (grad_act wrote its bits) and scales its outputs back; the staged values are
+          // then <= 16 and the x net's range flag covers the rest.  Otherwise (stand-alone gradient, fallback modes,
+          // weights outside the fp16 window): the exact fp32 matrix-core conv.
+          bool hx = false;
+          if (am) {
+            c.wpkh = h->packedh + cv.wt_h.w_hx2, c.hq = h->hq + 4 * cv.wt_h.hq, c.range_flag = flag, c.in_amax = am;
+            hx = conv_hx2_supported(c, CONV_S1);
+          }
+          if (hx) launch_conv_hx2(c, CONV_S1, s);
+          else launch_conv_mfma(c, CONV_S1, s);
         }
         g = gin;
       }
@@ -507,7 +531,12 @@ struct RatioGradRun {
   void run(const float* x, const float* y, float* gx, float* gy, float* log_ratio) {
     const int F = h->d.feature_dim;
     ab1 = ws->f((size_t)n * 256 * 2);
-    if (!dry) launch_fill_ab_identity(ab1, (size_t)n * 256, s);
+    amax = reinterpret_cast<unsigned*>(ws->f(64));
+    amax_used = 0;
+    if (!dry) {
+      launch_fill_ab_identity(ab1, (size_t)n * 256, s);
+      (void)hipMemsetAsync(amax, 0, 64 * sizeof(unsigned), s);
+    }
     float* feat = ws->f((size_t)n * 2 * F);
     std::vector<Kept> kx, ky;
     if (h->d.kind == RGFM_RATIO_MNIST28) {

@@ -134,7 +134,21 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2_kernel(const ConvArgs a,
   const int bw = (g.spt == 1) ? b0 : b0 + seg;
   const bool sample_ok = bw < a.B;
   const size_t pix0 = (g.spt == 1) ? (size_t)b0 * HW + (size_t)row0 * W : (size_t)bw * HW;
-  const float qmain = a.hq[0];
+  // ConvArgs::in_amax: power-of-two pre-scale of a raw input tensor whose magnitude is far from 1 (the gradients of the
+  // ratio estimator's reverse pass): max = f 2^e, f in [0.5, 1) -> the values are staged x 2^-e, the outputs x 2^e
+  float in_sc = 1.f, out_sc = 1.f;
+  if (a.in_amax) {
+    const float m = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)*a.in_amax));
+    if (m > 0.f && m < 3.0e38f) {
+      int e;
+      (void)frexpf(m, &e);
+      in_sc = ldexpf(1.f, -e), out_sc = ldexpf(1.f, e);
+    }
+    in_sc = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(in_sc)));
+    out_sc = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(out_sc)));
+  }
+  const float sa_raw = HX_SA * in_sc;
+  const float qmain = a.hq[0] * in_sc;
   f32x16 acc[2][NT];
   {
     float add0[NT];
@@ -318,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2_kernel(const ConvArgs a,
           v.z = silu_scaled(ks * (e1.x * v.z + e1.y));
           v.w = silu_scaled(ks * (e1.z * v.w + e1.w));
         } else {
-          v = v * HX_SA;
+          v = v * sa_raw;
         }
         amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         unsigned h0, l0, h1, l1;
@@ -467,7 +481,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2_kernel(const ConvArgs a,
   }
   PROF_T(te0);
   {
-    const float qinv = nch_skip ? a.hq_skip[1] : a.hq[1];
+    const float qinv = (nch_skip ? a.hq_skip[1] : a.hq[1]) * out_sc;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll

@@ -66,8 +66,9 @@ __device__ __forceinline__ float sigmoid_fast(float v) {
 template <bool GN>
 __global__ __launch_bounds__(256) void grad_act_kernel(const float* __restrict__ g, const float* __restrict__ z,
                                                        const float* __restrict__ scale, float* __restrict__ gz, int B, int S,
-                                                       int C, int mode) {
+                                                       int C, int mode, unsigned* __restrict__ amax) {
   const int C4 = C / 4;
+  float tmax = 0.f;  // largest |output| this thread wrote (ConvArgs::in_amax of the conv that reads gz)
   // u = ea z + eb per element (GN), scale factor of the result
   auto norm_of = [&](int b, int c4, f32x4& ea, f32x4& eb, f32x4& sc) {
     if (GN) {
@@ -122,7 +123,10 @@ __global__ __launch_bounds__(256) void grad_act_kernel(const float* __restrict__
           if (k == best) o[k][e] = gv[e] * (sg[k] * (1.0f + zv[k][e] * (1.0f - sg[k]))) * sc[e];
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(o[k], reinterpret_cast<f32x4*>(gz + off[k]));
+      for (int k = 0; k < 4; ++k) {
+        __builtin_nontemporal_store(o[k], reinterpret_cast<f32x4*>(gz + off[k]));
+        tmax = fmaxf(fmaxf(tmax, fmaxf(fabsf(o[k].x), fabsf(o[k].y))), fmaxf(fabsf(o[k].z), fabsf(o[k].w)));
+      }
     }
   } else {
     const size_t total = (size_t)B * S * S * C4;
@@ -149,13 +153,29 @@ __global__ __launch_bounds__(256) void grad_act_kernel(const float* __restrict__
         o[e] = gv[e] * (sg * (1.0f + zv[e] * (1.0f - sg))) * sc[e];
       }
       *reinterpret_cast<f32x4*>(gz + px * C + c4 * 4) = o;
+      tmax = fmaxf(fmaxf(tmax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+    }
+  }
+  if (amax) {  // (kernel-uniform) non-negative floats order like their bit patterns
+    // One atomic per WORKGROUP, and only when it would raise the word as this workgroup last saw it (a plain, possibly
+    // stale read: staleness costs an atomic, never a wrong maximum) -- one atomic per wave on one address serialised
+    // 131 k of them at the memory side and made this kernel 5 x slower.
+    __shared__ float smax[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o));
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = tmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float m = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+      if (m > __uint_as_float(__hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) atomicMax(amax, __float_as_uint(m));
     }
   }
 }
-void launch_grad_act(const float* g, const float* z, const float* scale, float* gz, int B, int S, int C, int mode, hipStream_t s) {
+void launch_grad_act(const float* g, const float* z, const float* scale, float* gz, int B, int S, int C, int mode, hipStream_t s,
+                     unsigned* amax) {
   const size_t total = (size_t)B * ((mode == 1 || mode == 3) ? (S / 2) * (S / 2) : S * S) * (C / 4);
   const unsigned blocks = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-  hipLaunchKernelGGL(grad_act_kernel<false>, dim3(blocks ? blocks : 1), dim3(256), 0, s, g, z, scale, gz, B, S, C, mode);
+  hipLaunchKernelGGL(grad_act_kernel<false>, dim3(blocks ? blocks : 1), dim3(256), 0, s, g, z, scale, gz, B, S, C, mode, amax);
 }
 // GroupNorm encoders: ab = the samples' scale/shift pairs; an odd map's last row and column are outside every 2x2
 // window (F.max_pool2d floors) and get a zero gradient
@@ -164,7 +184,7 @@ void launch_grad_act_gn(const float* g, const float* z, const float* ab, float* 
   if (pooled && (S & 1)) (void)hipMemsetAsync(gu, 0, (size_t)B * S * S * C * sizeof(float), s);
   const size_t total = (size_t)B * (pooled ? (S / 2) * (S / 2) : S * S) * (C / 4);
   const unsigned blocks = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-  hipLaunchKernelGGL(grad_act_kernel<true>, dim3(blocks ? blocks : 1), dim3(256), 0, s, g, z, ab, gu, B, S, C, mode);
+  hipLaunchKernelGGL(grad_act_kernel<true>, dim3(blocks ? blocks : 1), dim3(256), 0, s, g, z, ab, gu, B, S, C, mode, (unsigned*)nullptr);
 }
 
 // nn.GroupNorm backward, in place on gu (d/du, u = gamma xhat + beta) -> d/dz, one workgroup per (sample, group):

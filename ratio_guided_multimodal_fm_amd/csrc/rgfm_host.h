@@ -214,6 +214,7 @@ struct Modes {
   bool c8 = true;         // RGFM_HX2C=0: the 8x8 level on conv_mfma_hx2p_kernel (A/B switch)
   bool s2 = true;         // RGFM_HX2S=0: the Downsample convs on conv_mfma_hx2_kernel<*, CONV_S2, *> (A/B switch; same to 1e-6)
   bool pfmt = true;       // RGFM_HX2D=0: no P-format hand-over conv1 -> conv2 at the 16x16 / 8x8 levels (A/B switch)
+  bool rev_hx2 = true;    // RGFM_REV_HX2=0: the reverse convs of the gradient-guided sampler on the exact fp32 MFMA (A/B switch)
   bool graph = false;     // RGFM_GRAPH=1: the guided steps of the paired U-Net loop replayed from one captured hipGraph
                           // (bit-identical; measured 0.995-1.002x of the kernel-by-kernel path: the host is not the bottleneck)
 };
@@ -240,6 +241,8 @@ inline void refresh_modes() {
   e = getenv("RGFM_HX2D");
   m.pfmt = !(e && e[0] == '0');
   conv_hx2d_set(e && e[0] == '1' ? 1 : (e && e[0] == '2' ? 2 : 3));  // (1 / 2: one cut of conv_mfma_hx2d.hip everywhere -- A/B; process-wide, tools only)
+  e = getenv("RGFM_REV_HX2");
+  m.rev_hx2 = !(e && e[0] == '0');
   e = getenv("RGFM_GRAPH");
   m.graph = e && e[0] == '1';
   g_modes = m;

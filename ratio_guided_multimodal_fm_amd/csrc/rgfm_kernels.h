@@ -90,6 +90,11 @@ struct ConvArgs {
   // conv_mfma_hx2d.hip: the input ALREADY normalised, activated and split ("P format": [pixel][C0/16][h ch 0-7 | h ch
   // 8-15 | l ch 0-7 | l ch 8-15] fp16, 64 B per (pixel, 16-channel chunk), written by the producing conv's epilogue or
   // by launch_hx_presplit) -- staged by LDS-DMA only; `zeros` = 64 zero bytes on the device (the padding records' source)
+  // raw inputs far from unit scale (the gradients of the reverse pass, 1e-3 ... 1e-6): when set, *in_amax holds the bits
+  // of max |input| over the tensor (its producer's launch_grad_act wrote them) and the kernel stages 2^-e x the values
+  // (max = f 2^e, f in [0.5, 1)) and multiplies its outputs by 2^e -- the two-plane representation then keeps its 22 bits
+  // below the tensor's maximum.  conv_mfma_hx2_kernel (launch_conv_hx2), raw inputs without residual / skip only.
+  const unsigned* in_amax;
   const void* pin0;
   const void* zeros;
   // ... and the producing side: when set, the epilogue ALSO (out != null) or ONLY (out == null) writes the output in P
@@ -310,7 +315,9 @@ void launch_fill_ab_identity(float* ab, size_t n_pairs, hipStream_t s);  // (sca
 // gz[b,y,x,c] = route * silu'(z) * scale[c].  mode 0: g has z's shape; 1: g is the 2x2-max-pooled map's gradient
 // (routed to the first maximum of silu(z) in each window); 2: g is [B][C], the gradient of the global average of
 // silu(z); 3: g is [B][C], the gradient of the global average of the 2x2-max-pooled map (modes 2 then 1 in one)
-void launch_grad_act(const float* g, const float* z, const float* scale, float* gz, int B, int S, int C, int mode, hipStream_t s);
+// amax (optional): device word that receives (atomic max) the bits of the largest |gz| -- zero it before the launch
+void launch_grad_act(const float* g, const float* z, const float* scale, float* gz, int B, int S, int C, int mode, hipStream_t s,
+                     unsigned* amax = nullptr);
 // the GroupNorm encoders (RatioEstimator, 28x28): activation backward with per-sample scale/shift pairs, then the norm's own
 void launch_grad_act_gn(const float* g, const float* z, const float* ab, float* gu, int B, int S, int C, int mode, hipStream_t s);
 void launch_gn_bwd(float* gu, const float* z, const float* gamma, const float* mr, int B, int HW, int C, int groups, hipStream_t s);

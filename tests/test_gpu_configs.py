@@ -341,6 +341,49 @@ def test_grad_log_ratio_sampler_vs_oracle(dev):
     assert maxdiff(xs.cpu().numpy(), xn.cpu().numpy()) > 1e-5  # (the guidance does something)
 
 
+def test_grad_sampler_reverse_pass_on_the_two_plane_arithmetic(dev, monkeypatch):
+    """Inside the gradient-guided sampler the estimator's REVERSE convs run on the U-Nets' default arithmetic (two scaled
+    fp16 planes) with a measured power-of-two pre-scale of every gradient tensor (ConvArgs::in_amax; round 4).  One Euler
+    step with a huge gamma makes the update x1 - x0 ~ dt gamma grad log r, so the difference between the default run and
+    the run with the reverse convs on the exact fp32 MFMA (RGFM_REV_HX2=0; the same forward pass, hence the same max-pool
+    routing), divided by dt gamma, IS the error the reverse arithmetic puts into the gradient: it must be far inside the
+    gradient's stated tolerance (1e-4 of its largest entry).  The stand-alone gradient (always exact fp32) gives the
+    scale; against RGFM_CONV=f32 -- whose FORWARD pass differs at 1e-6, enough to flip a max-pool argmax here and there --
+    most samples must still agree."""
+    fm, fs, rr = make_module("mnist32", dev), make_module("svhn", dev), make_module("ratio_ms", dev)
+    B, S, gamma = 48, 100, 1.0e4
+    g = torch.Generator().manual_seed(41)
+    x0 = torch.randn(B, 1, 32, 32, generator=g).to(dev)
+    y0 = torch.randn(B, 3, 32, 32, generator=g).to(dev)
+    gx, gy, _ = rr._engine.grad_log_ratio(x0, y0)
+    res = {}
+    before = _engine.range_fallbacks
+    for tag, env in (("hx2", {}), ("rev32", {"RGFM_REV_HX2": "0"}), ("f32", {"RGFM_CONV": "f32"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        x, y = x0.clone(), y0.clone()
+        _engine.sample_pair_grad(fm, fs, rr, x, y, S, gamma, 10, 11)
+        res[tag] = (x.cpu().numpy().astype(np.float64), y.cpu().numpy().astype(np.float64))
+        for k in env:
+            monkeypatch.delenv(k)
+    assert _engine.range_fallbacks == before
+    dtg = gamma / S
+    mx, my = float(gx.abs().max()), float(gy.abs().max())
+    # (the update really is the gradient's: the exact run moved by ~ dt gamma g)
+    moved = np.abs(res["f32"][0] - x0.cpu().numpy()).max() / dtg
+    assert 0.5 * mx < moved < 2.0 * mx + 1e-3, (moved, mx)
+    ex = np.abs(res["hx2"][0] - res["rev32"][0]).max() / dtg
+    ey = np.abs(res["hx2"][1] - res["rev32"][1]).max() / dtg
+    print(f"gradient error of the two-plane reverse convs: x {ex:.2e} (max|g| {mx:.2e}), y {ey:.2e} (max|g| {my:.2e})")
+    assert 0.0 < ex + ey and ex < 1e-5 * mx and ey < 1e-5 * my, (ex, mx, ey, my)
+    # against the all-fp32 run: a flipped argmax moves a whole receptive field of one sample, so the statement is per
+    # sample -- most samples inside 1e-4 of the maximum
+    for k, m in ((0, mx), (1, my)):
+        d = (np.abs(res["hx2"][k] - res["f32"][k]) / dtg).reshape(B, -1).max(axis=1)
+        print(f"vs the all-fp32 run, plane {k}: {int((d < 1e-4 * m).sum())}/{B} samples inside 1e-4 max|g|, median {np.median(d):.2e}, max {d.max():.2e}")
+        assert np.median(d) < 1e-4 * m, (k, float(np.median(d)), m)
+
+
 # ------------------------------------------------------------------ checkpoints and CLIs (SURVEY 8f row 2)
 def _write_checkpoints(tmp_path):
     """The files the reference's trainers write, from synthetic weights: dict format for the two flow nets
