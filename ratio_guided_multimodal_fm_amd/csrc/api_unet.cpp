@@ -54,7 +54,25 @@ extern "C" int rgfm_unet_create(const rgfm_unet_desc* desc, const float* params_
   for (ConvW& w : h->down)  // ... and once more in plain tap order (same scale record: same weights)
     launch_pack_conv_hx2(h->params + w.w_raw, h->packedh + (w.w_hx9 - 1), h->hq + 4 * w.hq, w.cout, w.cin, 9, CONV_S1, s);
   for (ConvW& w : h->up) pack_one(h, w, CONV_S1, s), all.push_back(&w);
-  if (read_hx_flags(h->hq, h->n_hq, all, s) != RGFM_OK) return bail(RGFM_EHIP, "reading the fp16 scale records failed");
+  // the Upsample convs once more as ConvTranspose2d(4, 2, 1) weights (summed taps), packed in parity-class order
+  std::vector<ConvW> t2rec(h->up.size());
+  float* t2tmp = nullptr;
+  {
+    size_t mx = 0;
+    for (const ConvW& w : h->up) mx = std::max(mx, (size_t)w.cin * w.cout * 16);
+    if (mx && hipMalloc(&t2tmp, mx * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(upsample weights)");
+    for (size_t i = 0; i < h->up.size(); ++i) {
+      const ConvW& w = h->up[i];
+      launch_up2_as_deconv(h->params + w.w_raw, t2tmp, w.cout, w.cin, s);
+      launch_pack_conv_hx2(t2tmp, h->packedh + (w.w_t2 - 1), h->hq + 4 * w.hq_t2, w.cout, w.cin, 16, CONV_T2, s);
+      t2rec[i].hq = w.hq_t2;
+      all.push_back(&t2rec[i]);
+    }
+  }
+  const int rc_flags = read_hx_flags(h->hq, h->n_hq, all, s);  // (synchronises: the temporary is free)
+  if (t2tmp) (void)hipFree(t2tmp);
+  if (rc_flags != RGFM_OK) return bail(RGFM_EHIP, "reading the fp16 scale records failed");
+  for (size_t i = 0; i < h->up.size(); ++i) h->up[i].t2_ok = t2rec[i].hx_ok;
   {
     // (norm_params_ok: convs behind a GroupNorm with out-of-window parameters leave the fp16 path here)
     std::vector<float> host(n_floats);

@@ -39,7 +39,9 @@ __device__ __forceinline__ void fin_sample(const ConvArgs& a, int b, int lane, i
     const bool first = c < C0;
     const float* st = first ? a.stats_out : a.fin_stats1;
     const int cs = first ? C0 : a.fin_C1, cc = first ? c : c - C0;
-    const int np_total = first ? nparts0 : g.nparts;  // the partner is a plain map of the output's size (<= 16 parts)
+    // the partner is a plain map of the OUTPUT's size (<= 16 parts); behind a CONV_T2 launch g is the input raster and the
+    // host has checked that the output raster's parts are four times g's, size for size (rgfm_host.h: up_parts_match)
+    const int np_total = first ? nparts0 : (t2 ? 4 * g.nparts : g.nparts);
     // The channel's partials are fetched before any is used (one memory round trip).  The first source was
     // written during THIS launch, possibly by a CU of another XCD (whose L2 is not coherent with ours for plain
     // accesses): agent-scope atomic loads go to the coherence point.
@@ -54,7 +56,7 @@ __device__ __forceinline__ void fin_sample(const ConvArgs& a, int b, int lane, i
     for (int p = 0; p < 16; ++p) {
       // part sizes: a CONV_T2 output is four parity classes of the input raster g; a partner map of a stride-1 /
       // upsampling conv has the output raster g itself
-      const double np = p < np_total ? (double)geom_part_count(g, (first && t2) ? p % g.nparts : p) : 0.0;
+      const double np = p < np_total ? (double)geom_part_count(g, t2 ? p % g.nparts : p) : 0.0;
       const double mp = (double)__uint_as_float((unsigned)(bits[p] & 0xffffffffull));
       const double qp = (double)__uint_as_float((unsigned)(bits[p] >> 32));
       n += np;

@@ -175,6 +175,11 @@ struct ConvW {  // one packed conv
   int hq = 0;               // index of the conv's scale record {q, 1/q, s_w, eligible} in the handle's hq array
   bool hx_ok = false;       // weights inside the fp16 path's range (set after packing)
   int cin = 0, cout = 0, taps = 9;
+  // Upsample convs (nearest x 2, then 3x3: unet_flexible.py:107-108) a second time as the EQUIVALENT ConvTranspose2d(4, 2, 1)
+  // -- four 2x2-tap parity classes over the INPUT raster, 16 instead of 36 tap products per input pixel (launch_up2_as_deconv)
+  size_t w_t2 = 0;          // offset of its packed two-plane image, + 1 (0: none)
+  int hq_t2 = 0;            // its scale record
+  bool t2_ok = false;       // ... inside the fp16 path's range
 };
 
 struct ResW {
@@ -214,6 +219,7 @@ struct Modes {
   bool c8 = true;         // RGFM_HX2C=0: the 8x8 level on conv_mfma_hx2p_kernel (A/B switch)
   bool s2 = true;         // RGFM_HX2S=0: the Downsample convs on conv_mfma_hx2_kernel<*, CONV_S2, *> (A/B switch; same to 1e-6)
   bool pfmt = true;       // RGFM_HX2D=0: no P-format hand-over conv1 -> conv2 at the 16x16 / 8x8 levels (A/B switch)
+  bool up_t2 = true;      // RGFM_UP_T2=0: the Upsample convs as nine taps over the upsampled raster instead of four parity classes (A/B switch)
   bool rev_hx2 = true;    // RGFM_REV_HX2=0: the reverse convs of the gradient-guided sampler on the exact fp32 MFMA (A/B switch)
   bool graph = false;     // RGFM_GRAPH=1: the guided steps of the paired U-Net loop replayed from one captured hipGraph
                           // (bit-identical; measured 0.995-1.002x of the kernel-by-kernel path: the host is not the bottleneck)
@@ -241,6 +247,8 @@ inline void refresh_modes() {
   e = getenv("RGFM_HX2D");
   m.pfmt = !(e && e[0] == '0');
   conv_hx2d_set(e && e[0] == '1' ? 1 : (e && e[0] == '2' ? 2 : 3));  // (1 / 2: one cut of conv_mfma_hx2d.hip everywhere -- A/B; process-wide, tools only)
+  e = getenv("RGFM_UP_T2");
+  m.up_t2 = !(e && e[0] == '0');
   e = getenv("RGFM_REV_HX2");
   m.rev_hx2 = !(e && e[0] == '0');
   e = getenv("RGFM_GRAPH");
@@ -473,7 +481,12 @@ inline size_t plan_unet(const rgfm_unet_desc& d, rgfm_unet* h) {
     }
     if (l > 0) up_ch.push_back(ch);
   }
-  for (int uc : up_ch) up.push_back(conv(uc, uc, 9));
+  for (int uc : up_ch) {
+    ConvW w = conv(uc, uc, 9);
+    w.w_t2 = ph.take((size_t)uc * uc * 16 * 2) + 1;  // (the Upsample convs twice: nine taps, and the parity-class form)
+    w.hq_t2 = nhq++;
+    up.push_back(w);
+  }
   const size_t onw = c.take(ch), onb = c.take(ch);
   const size_t ocw = c.take((size_t)d.in_channels * ch * 9), ocb = c.take(d.in_channels);
   const size_t ocw_pk = pk.take((size_t)d.in_channels * ch * 9);
@@ -546,6 +559,17 @@ inline bool norm_params_ok(const std::vector<float>& host, size_t gw, size_t gb,
 }
 
 inline double conv_flops(int B, int HW, int cout, int kprod) { return 2.0 * B * HW * (double)cout * kprod; }
+
+// True when the statistics of a map written by a CONV_T2 launch over an S x S raster (4 parity classes x that raster's
+// parts) are indistinguishable, part for part, from those of a plain 2S x 2S map: same number of parts, same pixel
+// counts.  (32 <- 16 and 16 <- 8: 64-pixel parts on both sides.)
+inline bool up_parts_match(int S) {
+  const TileGeom gl = make_geom(S, S), gf = make_geom(2 * S, 2 * S);
+  if (gf.nparts != 4 * gl.nparts || gf.nparts > 16) return false;
+  for (int p = 0; p < gf.nparts; ++p)
+    if (geom_part_count(gf, p) != geom_part_count(gl, p % gl.nparts)) return false;
+  return true;
+}
 
 // A conv that has been described but not launched yet: if the next thing the walk asks for is the
 // GroupNorm finalize of its output, the finalize is attached to it (ConvArgs::fin_*: the last wave per
@@ -669,6 +693,16 @@ struct UNetRun {
     const int kprod = 9 * w.cin + (res_mode == 2 ? sk->cin : 0);
     fill_hx2(c, h->packedh, h->hq, h->range_flag, w, res_mode == 2 ? sk : nullptr);
     if (g_modes.conv == CONV_ARITH_HX2) c.range_flag = h->range_flag, c.small_check = raw_consumed ? 1 : 0;
+    if (mode == CONV_UP2 && g_modes.conv == CONV_ARITH_HX2 && g_modes.up_t2 && w.w_t2 && w.t2_ok && up_parts_match(a.S)) {
+      // nearest x 2 + 3x3 == ConvTranspose2d(4, 2, 1) with summed taps: the parity-class form over the INPUT raster
+      // (4 / 9 of the matrix work, a quarter of the halo per output).  Its statistics parts -- four classes x the input
+      // raster's parts -- have the sizes of the output raster's parts (up_parts_match), so readers see a plain map.
+      ConvArgs ct = c;
+      ct.g = make_geom(a.S, a.S);
+      ct.halo_px = ct.g.spt * (ct.g.th + 2) * (ct.g.W + 2);
+      ct.wpkh = h->packedh + (w.w_t2 - 1), ct.hq = h->hq + 4 * w.hq_t2;
+      if (conv_hx2_supported(ct, CONV_T2)) c = ct, mode = CONV_T2;
+    }
     bool p_in = false;
     if (norm && a.p_valid && !b) {
       // the producer (still pending) can hand this input over in P format: take it if conv_mfma_hx2d_kernel can run this

@@ -268,6 +268,9 @@ void conv_hx2q_set_tpw(int v);     // tools/kbench: force the tiles per workgrou
 void conv_hx2q_set_cut(int v);     // tools/kbench: force the workgroup cut (10 NG + NT: 11, 21, 12, 22)
 void conv_hx2q_set_all(int v);     // tools/kbench: 1 = every supported shape, not only those where it is the faster kernel
 void launch_conv_hx2q(const ConvArgs& a, int mode, hipStream_t s);
+// w [Cout][Cin][3][3] of "nearest-upsample x 2, then 3x3 conv" -> the ConvTranspose2d(4, 2, 1) weight K [Cin][Cout][4][4] of
+// the same linear map: K[ky][kx] = sum of w[i][j] over i in A(ky), j in A(kx), A = {2}, {1, 2}, {0, 1}, {0} (unet_kernels.hip)
+void launch_up2_as_deconv(const float* w, float* k, int Cout, int Cin, hipStream_t s);
 // packs w (mode CONV_S1: [Cout][Cin][taps]; CONV_S2: the phase-major stride-2 order; CONV_T2: a ConvTranspose2d
 // weight [Cin][Cout][4][4], taps ignored) and writes the scale record hq[4] (device)
 void launch_pack_conv_hx2(const float* w, void* out, float* hq, int Cout, int Cin, int taps, int mode, hipStream_t s);

@@ -241,6 +241,30 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const ConvInArgs a) {
   }
 }
 
+// Upsample.forward (unet_flexible.py:107-108) is conv3x3(nearest_x2(x)).  Output pixel 2i + a reads upsampled rows
+// 2i + a - 1 .. 2i + a + 1, i.e. source rows {i - 1, i, i} (a = 0) or {i, i, i + 1} (a = 1): two source rows per parity class
+// with the kernel rows that fall on the same source row ADDED -- a ConvTranspose2d(k = 4, s = 2, p = 1),
+// out[o] = sum_i x[i] K[o + 1 - 2 i], with K[3] = w[0], K[1] = w[1] + w[2], K[2] = w[0] + w[1], K[0] = w[2] per axis.  The zero
+// padding agrees (upsampled row -1 / 2H <-> source row -1 / H).  Sums in fp32, once, at create.
+__global__ void up2_as_deconv_kernel(const float* w, float* k, int Cout, int Cin) {
+  const size_t total = (size_t)Cout * Cin * 16;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int kx = (int)(i & 3), ky = (int)((i >> 2) & 3);
+    const size_t r = i >> 4;
+    const int co = (int)(r % Cout), ci = (int)(r / Cout);
+    const int lo_y = ky == 0 ? 2 : (ky == 1 ? 1 : 0), hi_y = ky == 0 ? 2 : (ky == 1 ? 2 : (ky == 2 ? 1 : 0));
+    const int lo_x = kx == 0 ? 2 : (kx == 1 ? 1 : 0), hi_x = kx == 0 ? 2 : (kx == 1 ? 2 : (kx == 2 ? 1 : 0));
+    const float* wp = w + ((size_t)co * Cin + ci) * 9;
+    float acc = 0.f;
+    for (int y = lo_y; y <= hi_y; ++y)
+      for (int x = lo_x; x <= hi_x; ++x) acc += wp[y * 3 + x];
+    k[i] = acc;
+  }
+}
+void launch_up2_as_deconv(const float* w, float* k, int Cout, int Cin, hipStream_t s) {
+  hipLaunchKernelGGL(up2_as_deconv_kernel, dim3(256), dim3(256), 0, s, w, k, Cout, Cin);
+}
+
 void launch_conv_in(const ConvInArgs& a, int cin, hipStream_t s) {
   const int per = (a.g.th + 2) * (a.g.W + 2);
   dim3 grid(geom_num_tiles(a.g, a.B));

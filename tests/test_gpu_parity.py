@@ -74,7 +74,7 @@ def test_unet_ragged_batches(dev, tag, B):
 
 
 @pytest.mark.parametrize("tag", ["g24", "g16", "g40"])
-@pytest.mark.parametrize("env", [{}, {"RGFM_CONV": "bx3"}, {"RGFM_CONV": "f32"}, {"RGFM_GN": "table"}, {"RGFM_HX2D": "0"}])
+@pytest.mark.parametrize("env", [{}, {"RGFM_CONV": "bx3"}, {"RGFM_CONV": "f32"}, {"RGFM_GN": "table"}, {"RGFM_HX2D": "0"}, {"RGFM_UP_T2": "0"}])
 def test_generic_flexible_unets(dev, tag, env, monkeypatch):
     """FlexibleUNet shapes outside the presets -- 24x24 (three tiles per sample: tile pairs straddle samples, 12
     statistics parts), 16x16 with four levels down to 2x2 maps and three blocks per level, 40x40 (tiles of 6 rows,
@@ -415,7 +415,9 @@ def test_full_size_arithmetic_modes_agree(dev, monkeypatch):
                                  {"RGFM_GN": "table"}, {"RGFM_GN": "table", "RGFM_FUSE_FIN": "0"},
                                  {"RGFM_CONV": "f32", "RGFM_FUSE_FIN": "0"},
                                  # the P-format hand-over conv1 -> conv2 (conv_mfma_hx2d.hip): off, and each of its two cuts everywhere
-                                 {"RGFM_HX2D": "0"}, {"RGFM_HX2D": "1"}, {"RGFM_HX2D": "2"}])
+                                 {"RGFM_HX2D": "0"}, {"RGFM_HX2D": "1"}, {"RGFM_HX2D": "2"},
+                                 # the Upsample convs as nine taps over the upsampled raster instead of four parity classes
+                                 {"RGFM_UP_T2": "0"}, {"RGFM_UP_T2": "0", "RGFM_GN": "table"}])
 @pytest.mark.parametrize("tag,B", [("svhn", 5), ("mnist32", 3)])
 def test_conv_variants_keep_parity(dev, env, tag, B, monkeypatch):
     """The alternative conv arithmetic (RGFM_CONV=bx3: three exact bf16 planes, the fp32-range fallback of the
