@@ -54,13 +54,17 @@ template <int NT, int MODE, int CFG, bool POUT = false>
 __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mfma_hx2p_kernel(const ConvArgs a, const int num_tiles) {
   constexpr bool PAIRN = CFG == HX2P_PAIRN || CFG == HX2P_PAIRN_HALF;
   constexpr bool HALF = CFG == HX2P_PAIRN_HALF;  // the packed weight blocks hold 128 channels, this workgroup takes 64 of them
-  constexpr int TPU = 3;                       // taps per unit
-  constexpr int UPC = 9 / TPU;                 // units per main chunk
+  // CONV_T2 (ConvTranspose2d(4, 2, 1) -- also the form the U-Net's Upsample convs take, rgfm_host.h): blockIdx.z is the
+  // output's parity class (py, px); its four taps read halo rows py, py + 1 and columns px, px + 1 of the INPUT raster's
+  // halo: units of two taps (one kernel row), two units per chunk
+  constexpr bool T2 = MODE == CONV_T2;
+  constexpr int TPU = T2 ? 2 : 3;              // taps per unit
+  constexpr int UPC = T2 ? 2 : 3;              // units per main chunk
   static_assert(!HALF || NT == 1, "HX2P_PAIRN_HALF: 2 groups x 32 channels");
   constexpr bool W4 = CFG == HX2P_FOUR_WAVES;
   constexpr int NTHR = W4 ? 256 : 512;
 
-  static_assert(MODE == CONV_S1 || MODE == CONV_UP2, "stride-2 / transposed convs run on conv_mfma_hx2_kernel");
+  static_assert(MODE == CONV_S1 || MODE == CONV_UP2 || MODE == CONV_T2, "stride-2 convs run on conv_mfma_hx2s_kernel / conv_mfma_hx2_kernel");
   constexpr int NG = PAIRN ? 2 : 1;            // channel groups per block
   constexpr int NA = (PAIRN || W4) ? 1 : 2;    // pixel tiles per block
   constexpr int NBLK = 32 * NT;                // channels per group
@@ -140,10 +144,11 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
     // columns still cover all 16 slot columns of the bank row, and the term no longer depends on the kernel row,
     // so the six offsets are computed once per block instead of per tap
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
+    for (int kxi = 0; kxi < 3; ++kxi) {
+      const int kx = T2 ? px + kxi : kxi;  // (T2: entry tx is halo column px + tx; entry 2 is not used)
       const int sw = ((x + kx) >> swz) & 3;
-      aofs[mt][kx][0] = (arec[mt] + kx) * HRW + ((hp_ ^ sw) & 3) * 16;
-      aofs[mt][kx][1] = (arec[mt] + kx) * HRW + (((2 + hp_) ^ sw) & 3) * 16;
+      aofs[mt][kxi][0] = (arec[mt] + kx) * HRW + ((hp_ ^ sw) & 3) * 16;
+      aofs[mt][kxi][1] = (arec[mt] + kx) * HRW + (((2 + hp_) ^ sw) & 3) * 16;
     }
   }
   int bbase[NT], bsw[NT];
@@ -309,7 +314,9 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
   constexpr int UBS = TPU * TAPS;
   const int wblk = HALF ? (int)blockIdx.y >> 1 : (int)blockIdx.y;
   const int whalf = HALF ? ((int)blockIdx.y & 1) * TAPB : 0;
-  const char* wpk = reinterpret_cast<const char*>(a.wpkh) + (size_t)wblk * nmain * 9 * TAPS + whalf;
+  // (T2: [parity class][channel block][chunk][4 taps])
+  const int wblocks = HALF ? (int)gridDim.y >> 1 : (int)gridDim.y;
+  const char* wpk = reinterpret_cast<const char*>(a.wpkh) + ((size_t)(T2 ? pc * wblocks : 0) + wblk) * nmain * (UPC * TPU) * TAPS + whalf;
   const char* wsk = reinterpret_cast<const char*>(a.wskiph) + (size_t)wblk * nskip * TAPS + whalf;
 
   f32x4 ra[MAXIT], rb[NB];
@@ -530,7 +537,7 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
     // count loads across the loop's back edge and waits for vmcnt(0) before the first use (or re-use) of a register
     // fetched in an earlier unit: with a fresh fetch already in flight that would be a full memory round trip
     // inside every staging phase.
-    constexpr int NU = (U < 0) ? MAXIT : (MAXIT + 2 - U) / 3;  // items of this unit: j = U, U + 3, ... (all of them in a one-tap unit)
+    constexpr int NU = (U < 0) ? MAXIT : (MAXIT + UPC - 1 - U) / UPC;  // items of this unit: j = U, U + UPC, ... (all of them in a one-tap unit)
     const bool have1 = c + 1 < ntot, have2 = c + 2 < ntot;
     const bool xf = gn_on && c + 1 < nmain;
     hx_u32x4 dn = {0u, 0u, 0u, 0u};
@@ -539,7 +546,7 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
     if (have1 && xf) {
 #pragma unroll
       for (int k = 0; k < NU; ++k) {
-        const int j = (U < 0) ? k : U + 3 * k;
+        const int j = (U < 0) ? k : U + UPC * k;
         if (j < nitems) table_a(c + 1, j, e0[k], e1[k]);
       }
     }
@@ -547,14 +554,14 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
     if (have1) {
 #pragma unroll
       for (int k = 0; k < NU; ++k) {
-        const int j = (U < 0) ? k : U + 3 * k;
+        const int j = (U < 0) ? k : U + UPC * k;
         if (j < nitems) commit_a(c + 1, j, xf, e0[k], e1[k]);
       }
     }
     if (have2) {
 #pragma unroll
       for (int k = 0; k < NU; ++k) {
-        const int j = (U < 0) ? k : U + 3 * k;
+        const int j = (U < 0) ? k : U + UPC * k;
         if (j < nitems) issue_a(dn, j);
       }
     }
@@ -670,34 +677,36 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
     const char* sAc = smemp + (c & 1) * abytes;
     const char* sBu = sB + (gidx & 1) * UB;
     if (role == 0) stage(c, u_tag, gidx);
-    const char* sArow = sAc + U * WR * HRW;
+    const char* sArow = sAc + (T2 ? py + U : U) * WR * HRW;
     tap(sArow, sBu, K0{});
     tap(sArow, sBu + TAPB, K1{});
-    tap(sArow, sBu + 2 * TAPB, K2{});
+    if constexpr (!T2) tap(sArow, sBu + 2 * TAPB, K2{});
     if (role != 0) stage(c, u_tag, gidx);
     if (gidx != G - 1) __syncthreads();
     ++gidx;
   };
   int c0 = 0;
-  if (gn_on && nitems >= 3) {
+  if constexpr (!T2) {
+    if (gn_on && nitems >= 3) {
 #pragma unroll 1
-    for (; c0 < nmain - 1; ++c0) {
-      unit_fast(c0, U0{});
-      unit_fast(c0, U1{});
-      unit_fast(c0, U2{});
-    }
-    if (nskip == 0) {
-      unit_tail(c0, U0{});
-      unit_tail(c0, U1{});
-      unit_tail(c0, U2{});
-      ++c0;
+      for (; c0 < nmain - 1; ++c0) {
+        unit_fast(c0, U0{});
+        unit_fast(c0, U1{});
+        unit_fast(c0, U2{});
+      }
+      if (nskip == 0) {
+        unit_tail(c0, U0{});
+        unit_tail(c0, U1{});
+        unit_tail(c0, U2{});
+        ++c0;
+      }
     }
   }
 #pragma unroll 1
   for (int c = c0; c < nmain; ++c) {
     unit(c, U0{});
     unit(c, U1{});
-    unit(c, U2{});
+    if constexpr (!T2) unit(c, U2{});
   }
   if (nskip) {  // the 1x1 skip weights carry their own scale: q_main -> q_skip
     const float rs = a.hq_skip[0] * a.hq[1];
@@ -899,11 +908,11 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
 
 // ---------------------------------------------------------------- host side
 static int hx2p_halo(const ConvArgs& a) { return a.g.spt * (a.g.th + 2) * (a.g.W + 2); }
-static size_t hx2p_lds_bytes(const ConvArgs& a, int cfg) {
+static size_t hx2p_lds_bytes(const ConvArgs& a, int cfg, int mode) {
   const bool halfc = cfg == HX2P_PAIRN_HALF;
   const int nt = halfc ? 1 : ((a.Cout % 64 == 0) ? 2 : 1);
   const int na = cfg == HX2P_TWO_TILES ? 2 : 1, nbt = 32 * nt * ((cfg == HX2P_PAIRN || halfc) ? 2 : 1);
-  const int tpu = 3;
+  const int tpu = mode == CONV_T2 ? 2 : 3;
   size_t bytes = (size_t)2 * (na * hx2p_halo(a) + 1) * HRW + (size_t)2 * tpu * nbt * HRW;  // two halo buffers (+ pad record) + two weight units
   if (a.gn_stats0 || a.ab) bytes += (size_t)(na * a.g.spt + 1) * (a.C0 + a.C1) * 2 * sizeof(float);  // scale/shift table + the zero row
   bytes += (size_t)(a.C0 + a.C1 + (a.res_mode == 2 ? a.R0 + a.R1 : 0));                    // 16 bytes per 16-channel chunk: descriptors
@@ -922,11 +931,11 @@ void conv_hx2p_set_w4(int v) { g_hx2p_w4 = v; }
 // launches with fewer workgroups than this are cut finer (0: never); the CU count
 static int g_hx2p_half = 256;
 void conv_hx2p_set_half(int v) { g_hx2p_half = v; }
-static int hx2p_cfg(const ConvArgs& a) {
-  const bool fits = hx2p_lds_bytes(a, HX2P_FOUR_WAVES) <= 80 * 1024;  // two workgroups per CU
+static int hx2p_cfg(const ConvArgs& a, int mode) {
+  const bool fits = hx2p_lds_bytes(a, HX2P_FOUR_WAVES, mode) <= 80 * 1024;  // two workgroups per CU
   if (g_hx2p_w4 == 2 && fits) return HX2P_FOUR_WAVES;
   if (g_hx2p_w4 == 1 && fits && a.Cout % 128 != 0) return HX2P_FOUR_WAVES;
-  const int tiles = geom_num_tiles(a.g, a.B);
+  const int tiles = geom_num_tiles(a.g, a.B) * (mode == CONV_T2 ? 4 : 1);  // (workgroups: a parity class each)
   if (a.Cout % 128 != 0) {
     const int wgs = ((tiles + 1) / 2) * (a.Cout / (32 * ((a.Cout % 64 == 0) ? 2 : 1)));
     return (g_hx2p_half && wgs < g_hx2p_half) ? HX2P_FOUR_WAVES : HX2P_TWO_TILES;
@@ -938,22 +947,23 @@ static int hx2p_cfg(const ConvArgs& a) {
 
 // the pipelined kernel takes: stride-1 / upsampling convs whose input norm (if any) is the consumer-side one
 bool conv_hx2p_supported(const ConvArgs& a, int mode) {
-  if (mode != CONV_S1 && mode != CONV_UP2) return false;
+  if (mode != CONV_S1 && mode != CONV_UP2 && mode != CONV_T2) return false;
+  if (mode == CONV_T2 && (a.res_mode != 0 || a.pout)) return false;
   if (!conv_hx2_supported(a, mode)) return false;
   if (a.gn_stats0 && !conv_hx2_gn_supported(a, mode)) return false;
-  return hx2p_halo(a) <= 448 && hx2p_lds_bytes(a, hx2p_cfg(a)) <= 160 * 1024;
+  return hx2p_halo(a) <= 448 && hx2p_lds_bytes(a, hx2p_cfg(a, mode), mode) <= 160 * 1024;
 }
 
 int conv_hx2p_init() {
   int rc = 0;
 #define RAISEP(NTV, M, P) rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_hx2p_kernel<NTV, M, P>), \
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-  RAISEP(1, CONV_S1, HX2P_TWO_TILES); RAISEP(1, CONV_UP2, HX2P_TWO_TILES);
-  RAISEP(2, CONV_S1, HX2P_TWO_TILES); RAISEP(2, CONV_UP2, HX2P_TWO_TILES);
-  RAISEP(2, CONV_S1, HX2P_PAIRN); RAISEP(2, CONV_UP2, HX2P_PAIRN);
-  RAISEP(1, CONV_S1, HX2P_PAIRN_HALF); RAISEP(1, CONV_UP2, HX2P_PAIRN_HALF);
-  RAISEP(1, CONV_S1, HX2P_FOUR_WAVES); RAISEP(1, CONV_UP2, HX2P_FOUR_WAVES);
-  RAISEP(2, CONV_S1, HX2P_FOUR_WAVES); RAISEP(2, CONV_UP2, HX2P_FOUR_WAVES);
+  RAISEP(1, CONV_S1, HX2P_TWO_TILES); RAISEP(1, CONV_UP2, HX2P_TWO_TILES); RAISEP(1, CONV_T2, HX2P_TWO_TILES);
+  RAISEP(2, CONV_S1, HX2P_TWO_TILES); RAISEP(2, CONV_UP2, HX2P_TWO_TILES); RAISEP(2, CONV_T2, HX2P_TWO_TILES);
+  RAISEP(2, CONV_S1, HX2P_PAIRN); RAISEP(2, CONV_UP2, HX2P_PAIRN); RAISEP(2, CONV_T2, HX2P_PAIRN);
+  RAISEP(1, CONV_S1, HX2P_PAIRN_HALF); RAISEP(1, CONV_UP2, HX2P_PAIRN_HALF); RAISEP(1, CONV_T2, HX2P_PAIRN_HALF);
+  RAISEP(1, CONV_S1, HX2P_FOUR_WAVES); RAISEP(1, CONV_UP2, HX2P_FOUR_WAVES); RAISEP(1, CONV_T2, HX2P_FOUR_WAVES);
+  RAISEP(2, CONV_S1, HX2P_FOUR_WAVES); RAISEP(2, CONV_UP2, HX2P_FOUR_WAVES); RAISEP(2, CONV_T2, HX2P_FOUR_WAVES);
 #undef RAISEP
 #define RAISEPP(NTV, P) rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_hx2p_kernel<NTV, CONV_S1, P, true>), \
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
@@ -967,11 +977,11 @@ void launch_conv_hx2p(const ConvArgs& a_in, int mode, hipStream_t s) {
   a.halo_px = hx2p_halo(a_in);
   const int nt = (a.Cout % 64 == 0) ? 2 : 1;
   const int tiles = geom_num_tiles(a.g, a.B);
-  const int cfg = hx2p_cfg(a);
+  const int cfg = hx2p_cfg(a, mode);
   if (cfg == HX2P_PAIRN_HALF) a.fin_expected *= 2;  // (producer-side finalize: twice the 4-wave groups along the channels arrive)
   dim3 grid(cfg == HX2P_TWO_TILES ? (tiles + 1) / 2 : tiles,
-            cfg == HX2P_PAIRN ? a.Cout / 128 : (cfg == HX2P_PAIRN_HALF ? a.Cout / 64 : a.Cout / (32 * nt)), 1);
-  const size_t lds = hx2p_lds_bytes(a, cfg);
+            cfg == HX2P_PAIRN ? a.Cout / 128 : (cfg == HX2P_PAIRN_HALF ? a.Cout / 64 : a.Cout / (32 * nt)), mode == CONV_T2 ? 4 : 1);
+  const size_t lds = hx2p_lds_bytes(a, cfg, mode);
 #define LAUNCHP(NTV, M, P) hipLaunchKernelGGL((conv_mfma_hx2p_kernel<NTV, M, P>), grid, dim3(P == HX2P_FOUR_WAVES ? 256 : 512), lds, s, a, tiles)
   if (a.pout) {  // (the walk has checked hx2p_pout_supported: 16x16 stride-1, 64 / 128 / 256 output channels)
 #define LAUNCHPP(NTV, P) hipLaunchKernelGGL((conv_mfma_hx2p_kernel<NTV, CONV_S1, P, true>), grid, dim3(P == HX2P_FOUR_WAVES ? 256 : 512), lds, s, a, tiles)
@@ -985,6 +995,7 @@ void launch_conv_hx2p(const ConvArgs& a_in, int mode, hipStream_t s) {
 #define LAUNCHM(NTV, P)                           \
   do {                                            \
     if (mode == CONV_S1) LAUNCHP(NTV, CONV_S1, P); \
+    else if (mode == CONV_T2) LAUNCHP(NTV, CONV_T2, P); \
     else LAUNCHP(NTV, CONV_UP2, P);               \
   } while (0)
   if (cfg == HX2P_PAIRN) LAUNCHM(2, HX2P_PAIRN);
