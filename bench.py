@@ -369,6 +369,10 @@ def main():
                 "peak_nominal": peak, "peak_sustained": sustained,
                 "frac_sustained": (ach / sustained) if sustained else None,
                 "kernel": kern, "peak_basis": basis, "conv_arithmetic": conv_mode,
+                # `achieved` counts the REFERENCE's conv FLOPs.  On the default arithmetic the three Upsample convs
+                # (nearest x 2 + 3x3: 13 % of those FLOPs) run as the equivalent ConvTranspose2d(4, 2, 1), 4 / 9 of the products
+                # (RGFM_UP_T2): what the matrix cores execute is this fraction of the algorithmic count
+                "executed_over_algorithmic": (0.928 if (conv_mode == "hx2" and os.environ.get("RGFM_UP_T2", "1") != "0") else 1.0),
                 "launches": int(conv_n), "avg_launch_us": 1e3 * conv_sum_ms / max(conv_n, 1),
                 "busy_ms": conv_ms, "sum_launch_ms": conv_sum_ms,
                 "timing": "hipEvents (created before the timed region) on the launch streams; achieved = algorithmic "
