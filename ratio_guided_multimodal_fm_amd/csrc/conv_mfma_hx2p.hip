@@ -388,6 +388,21 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
     }
   };
 
+  // ---- pipeline fill, part 1: the raw halo of chunk 0 (always the first channels of in0) and the weights of unit 0 are
+  // requested HERE, ahead of the GroupNorm table: their round trip runs under the table's (statistics fetch, fp64
+  // reduction, barrier) instead of behind it
+  // (the cuts whose 64-channel wave tiles leave no registers for requests in flight across the table -- two tiles or four
+  // waves with NT = 2: the compiler spills them -- request behind the table's barrier as before)
+  constexpr bool EARLY = PAIRN || NT == 1;
+  const unsigned long long in0_bits = reinterpret_cast<unsigned long long>(a.in0);
+  const hx_u32x4 d0 = {(unsigned)in0_bits, (unsigned)(in0_bits >> 32), (unsigned)a.C0, 0u};
+  if constexpr (EARLY) {
+#pragma unroll
+    for (int j = 0; j < MAXIT; ++j)
+      if (j < nitems) issue_a(d0, j);
+    issue_b(0);
+  }
+
   if (a.gn_stats0 && gn_active) {
     // ---- consumer-side GroupNorm: scale/shift of this block's sample(s) from the producers' partial statistics.
     // Up to all waves take part: the block's R = NA * spt table rows (one per sample slot) are split over the NW waves,
@@ -469,13 +484,14 @@ __global__ __launch_bounds__(CFG == HX2P_FOUR_WAVES ? 256 : 512, 2) void conv_mf
   }
   __syncthreads();  // the scale/shift table and the chunk descriptors are complete
   const bool gn_on = has_tab;
-  // ---- pipeline fill: halo of chunk 0 and weights of unit 0 in LDS, raw halo of chunk 1 and weights of unit 1 in registers
+  // ---- pipeline fill, part 2: halo of chunk 0 and weights of unit 0 into LDS, raw halo of chunk 1 and weights of unit 1 in registers
   {
-    const hx_u32x4 d0 = chunk_desc(0);
+    if constexpr (!EARLY) {
 #pragma unroll
-    for (int j = 0; j < MAXIT; ++j)
-      if (j < nitems) issue_a(d0, j);
-    issue_b(0);
+      for (int j = 0; j < MAXIT; ++j)
+        if (j < nitems) issue_a(d0, j);
+      issue_b(0);
+    }
 #pragma unroll
     for (int j = 0; j < MAXIT; ++j)
       if (j < nitems) {
