@@ -306,6 +306,7 @@ inline int ensure_init() {
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, dev) == hipSuccess) d.num_cus = p.multiProcessorCount;
     conv_hx2p_set_half(d.num_cus);  // launches with fewer 128-channel workgroups than CUs take 64-channel workgroups
+    if (const char* e = getenv("RGFM_HX2P_HALF")) conv_hx2p_set_half(atoi(e));  // (A/B of that threshold; every cut gives the same bits)
     HIP_TRY(hipStreamCreateWithFlags(&d.side, hipStreamNonBlocking));
     HIP_TRY(hipMalloc(&d.zeros, 256));
     HIP_TRY(hipMemset(d.zeros, 0, 256));
