@@ -111,6 +111,9 @@ int rgfm_unet_num_activations(const rgfm_unet* h, int* n);
  * pre-normalised pre-split "P format" (conv_mfma_hx2d.hip) instead of as an fp32 map.  Lets a
  * test see that the hand-over is really taken (its results are the fp32 hand-over's to the last bit or two). */
 int rgfm_unet_p_handovers(const rgfm_unet* h, int* blocks);
+/* Debug / test hook: how many convs of the handle's LATEST network walk were described for the Winograd F(2x2, 3x3) kernel
+ * (conv_mfma_hx2w.hip; opt-in: RGFM_WINO=1). */
+int rgfm_unet_wino_convs(const rgfm_unet* h, int* convs);
 int rgfm_unet_activation_shape(const rgfm_unet* h, int index, int* channels, int* height, int* width);
 int rgfm_unet_read_activation(rgfm_unet* h, int index, int batch, const void* ws, float* out_dev,
                               rgfm_stream_t stream);

@@ -42,6 +42,7 @@ SIGNATURES = {
                                   c_size_t, c_void_p]),
     "rgfm_unet_set_trace": (c_int, [c_void_p, c_int]),
     "rgfm_unet_p_handovers": (c_int, [c_void_p, P(c_int)]),
+    "rgfm_unet_wino_convs": (c_int, [c_void_p, P(c_int)]),
     "rgfm_unet_time_embedding": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rgfm_unet_num_activations": (c_int, [c_void_p, P(c_int)]),
     "rgfm_unet_activation_shape": (c_int, [c_void_p, c_int, P(c_int), P(c_int), P(c_int)]),

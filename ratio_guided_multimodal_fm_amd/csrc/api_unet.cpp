@@ -54,12 +54,21 @@ extern "C" int rgfm_unet_create(const rgfm_unet_desc* desc, const float* params_
   for (ConvW& w : h->down)  // ... and once more in plain tap order (same scale record: same weights)
     launch_pack_conv_hx2(h->params + w.w_raw, h->packedh + (w.w_hx9 - 1), h->hq + 4 * w.hq, w.cout, w.cin, 9, CONV_S1, s);
   for (ConvW& w : h->up) pack_one(h, w, CONV_S1, s), all.push_back(&w);
-  // the Upsample convs once more as ConvTranspose2d(4, 2, 1) weights (summed taps), packed in parity-class order
+  // the Upsample convs once more as ConvTranspose2d(4, 2, 1) weights (summed taps), packed in parity-class order; the
+  // ResBlock convs once more as Winograd images (one scratch array serves both)
   std::vector<ConvW> t2rec(h->up.size());
+  std::vector<ConvW*> wino;
+  for (auto* v : {&h->enc, &h->mid, &h->dec})
+    for (ResW& r : *v) {
+      if (r.c1.w_w) wino.push_back(&r.c1);
+      if (r.c2.w_w) wino.push_back(&r.c2);
+    }
+  std::vector<ConvW> wrec(wino.size());
   float* t2tmp = nullptr;
   {
     size_t mx = 0;
     for (const ConvW& w : h->up) mx = std::max(mx, (size_t)w.cin * w.cout * 16);
+    for (const ConvW* w : wino) mx = std::max(mx, (size_t)w->cin * w->cout * 16);
     if (mx && hipMalloc(&t2tmp, mx * sizeof(float)) != hipSuccess) return bail(RGFM_ENOMEM, "hipMalloc(upsample weights)");
     for (size_t i = 0; i < h->up.size(); ++i) {
       const ConvW& w = h->up[i];
@@ -68,11 +77,18 @@ extern "C" int rgfm_unet_create(const rgfm_unet_desc* desc, const float* params_
       t2rec[i].hq = w.hq_t2;
       all.push_back(&t2rec[i]);
     }
+    for (size_t i = 0; i < wino.size(); ++i) {
+      const ConvW& w = *wino[i];
+      launch_pack_conv_hx2w(h->params + w.w_raw, h->packedh + (w.w_w - 1), h->hq + 4 * w.hq_w, t2tmp, w.cout, w.cin, s);
+      wrec[i].hq = w.hq_w;
+      all.push_back(&wrec[i]);
+    }
   }
   const int rc_flags = read_hx_flags(h->hq, h->n_hq, all, s);  // (synchronises: the temporary is free)
   if (t2tmp) (void)hipFree(t2tmp);
   if (rc_flags != RGFM_OK) return bail(RGFM_EHIP, "reading the fp16 scale records failed");
   for (size_t i = 0; i < h->up.size(); ++i) h->up[i].t2_ok = t2rec[i].hx_ok;
+  for (size_t i = 0; i < wino.size(); ++i) wino[i]->w_ok = wrec[i].hx_ok;
   {
     // (norm_params_ok: convs behind a GroupNorm with out-of-window parameters leave the fp16 path here)
     std::vector<float> host(n_floats);
@@ -216,6 +232,11 @@ void act_table(const rgfm_unet* h, std::vector<std::pair<int, int>>& t) {
 extern "C" int rgfm_unet_p_handovers(const rgfm_unet* h, int* blocks) {
   if (!h || !blocks) return fail(RGFM_EINVAL, "null argument");
   *blocks = h->p_handovers;
+  return RGFM_OK;
+}
+extern "C" int rgfm_unet_wino_convs(const rgfm_unet* h, int* convs) {
+  if (!h || !convs) return fail(RGFM_EINVAL, "null argument");
+  *convs = h->wino_convs;
   return RGFM_OK;
 }
 

@@ -646,6 +646,10 @@ __global__ void hx2_scale_kernel(const float* w, size_t n, float* hq) {
   }
 }
 
+void hx2_scale_launch(const float* w, size_t n, float* hq, hipStream_t s) {  // (for conv_mfma_hx2w.hip's transformed weights)
+  hipLaunchKernelGGL(hx2_scale_kernel, dim3(1), dim3(256), 0, s, w, n, hq);
+}
+
 __device__ __forceinline__ void hsplit1(float v, unsigned short& h, unsigned short& l) {
   unsigned ph, pl;
   hsplit2(v, 0.f, ph, pl);

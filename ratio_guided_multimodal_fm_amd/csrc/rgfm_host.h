@@ -177,6 +177,10 @@ struct ConvW {  // one packed conv
   int cin = 0, cout = 0, taps = 9;
   // Upsample convs (nearest x 2, then 3x3: unet_flexible.py:107-108) a second time as the EQUIVALENT ConvTranspose2d(4, 2, 1)
   // -- four 2x2-tap parity classes over the INPUT raster, 16 instead of 36 tap products per input pixel (launch_up2_as_deconv)
+  // ResBlock convs with Cout % 64 == 0 a second time as Winograd F(2x2, 3x3) images (conv_mfma_hx2w.hip)
+  size_t w_w = 0;           // offset (fp16 elements) of the transformed two-plane image, + 1 (0: none)
+  int hq_w = 0;             // its scale record
+  bool w_ok = false;        // ... inside the fp16 path's range
   size_t w_t2 = 0;          // offset of its packed two-plane image, + 1 (0: none)
   int hq_t2 = 0;            // its scale record
   bool t2_ok = false;       // ... inside the fp16 path's range
@@ -219,6 +223,8 @@ struct Modes {
   bool c8 = true;         // RGFM_HX2C=0: the 8x8 level on conv_mfma_hx2p_kernel (A/B switch)
   bool s2 = true;         // RGFM_HX2S=0: the Downsample convs on conv_mfma_hx2_kernel<*, CONV_S2, *> (A/B switch; same to 1e-6)
   bool pfmt = true;       // RGFM_HX2D=0: no P-format hand-over conv1 -> conv2 at the 16x16 / 8x8 levels (A/B switch)
+  bool wino = false;      // RGFM_WINO=1: the Winograd form of the long-K stride-1 convs (conv_mfma_hx2w.hip) -- opt-in: faster per
+                          // layer in isolation at 32x32, slower on the whole bench
   bool up_t2 = true;      // RGFM_UP_T2=0: the Upsample convs as nine taps over the upsampled raster instead of four parity classes (A/B switch)
   bool rev_hx2 = true;    // RGFM_REV_HX2=0: the reverse convs of the gradient-guided sampler on the exact fp32 MFMA (A/B switch)
   bool graph = false;     // RGFM_GRAPH=1: the guided steps of the paired U-Net loop replayed from one captured hipGraph
@@ -247,6 +253,8 @@ inline void refresh_modes() {
   e = getenv("RGFM_HX2D");
   m.pfmt = !(e && e[0] == '0');
   conv_hx2d_set(e && e[0] == '1' ? 1 : (e && e[0] == '2' ? 2 : 3));  // (1 / 2: one cut of conv_mfma_hx2d.hip everywhere -- A/B; process-wide, tools only)
+  e = getenv("RGFM_WINO");
+  m.wino = e && e[0] == '1';
   e = getenv("RGFM_UP_T2");
   m.up_t2 = !(e && e[0] == '0');
   e = getenv("RGFM_REV_HX2");
@@ -301,7 +309,7 @@ inline int ensure_init() {
   DevState& d = g_dev[dev];
   if (!d.init) {
     if (conv_mfma_init() != 0 || conv_bx3_init() != 0 || conv_hx2_init() != 0 || conv_hx2p_init() != 0 || conv_hx2q_init() != 0 ||
-        conv_hx2s_init() != 0 || conv_hx2c_init() != 0 || conv_hx2d_init() != 0 || guid_apply_init() != 0)
+        conv_hx2s_init() != 0 || conv_hx2c_init() != 0 || conv_hx2d_init() != 0 || conv_hx2w_init() != 0 || guid_apply_init() != 0)
       return fail(RGFM_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, dev) == hipSuccess) d.num_cus = p.multiProcessorCount;
@@ -334,9 +342,20 @@ inline bool p_producer_ok(const ConvArgs& c, int mode) {
   return false;
 }
 
+// Where the Winograd form is the faster kernel (tools/kbench, B = 512, profiles/r04_kbench/hx2w_vs_direct.txt): its K loop
+// costs less per chunk than the direct kernels', its epilogue (the output transform through LDS) more -- so the long-K
+// layers: 128 or more input channels.  By layer shape only, never by batch.
+inline bool hx2w_pays(const ConvArgs& c) {
+  return c.wpkw != nullptr && c.C0 + c.C1 >= 128;
+}
+
 inline void launch_conv(const ConvArgs& c, int mode, hipStream_t s) {
   if (c.pin0) {  // (P-format input: only conv_mfma_hx2d_kernel reads it; the walk has checked conv_hx2d_supported)
     launch_conv_hx2d(c, s);
+    return;
+  }
+  if (g_modes.conv == CONV_ARITH_HX2 && g_modes.pipelined && g_modes.wino && hx2w_pays(c) && conv_hx2w_supported(c, mode)) {
+    launch_conv_hx2w(c, s);
     return;
   }
   if (g_modes.conv == CONV_ARITH_HX2 && g_modes.pipelined && g_modes.s2 && conv_hx2s_supported(c, mode)) launch_conv_hx2s(c, s);
@@ -403,6 +422,7 @@ struct rgfm_unet {
   std::vector<ConvW> down, up;
   int final_ch = 0;
   bool trace = false;
+  int wino_convs = 0;   // convs of the latest walk described for the Winograd kernel (rgfm_unet_wino_convs)
   int p_handovers = 0;  // ResBlocks of the latest walk whose conv1 -> conv2 hand-over took the P format (rgfm_unet_p_handovers)
   struct Act {
     float* data;
@@ -443,6 +463,10 @@ inline size_t plan_unet(const rgfm_unet_desc& d, rgfm_unet* h) {
     r.tw = c.take((size_t)cout * temb), r.tb = c.take(cout);
     r.n2w = c.take(cout), r.n2b = c.take(cout);
     r.c2 = conv(cout, cout, 9);
+    if (cout % 64 == 0 && cin % KC == 0) {  // the Winograd images (16 positions instead of 9 taps)
+      r.c1.w_w = ph.take((size_t)cout * cin * 16 * 2) + 1, r.c1.hq_w = nhq++;
+      r.c2.w_w = ph.take((size_t)cout * cout * 16 * 2) + 1, r.c2.hq_w = nhq++;
+    }
     r.has_skip = cin != cout;
     if (r.has_skip) r.sk = conv(cin, cout, 1);
     r.temb_off = temb_off;
@@ -545,6 +569,7 @@ inline void fill_hx2(ConvArgs& c, const unsigned short* packedh, const float* hq
   if (!w.hx_ok || (sk && !sk->hx_ok)) return;
   c.wpkh = packedh + w.w_hx2, c.hq = hq + 4 * w.hq, c.range_flag = flag;
   if (w.w_hx9) c.wpkh9 = packedh + (w.w_hx9 - 1);
+  if (w.w_w && w.w_ok && !sk) c.wpkw = packedh + (w.w_w - 1), c.hqw = hq + 4 * w.hq_w;
   if (sk) c.wskiph = packedh + sk->w_hx2, c.hq_skip = hq + 4 * sk->hq;
 }
 
@@ -726,6 +751,7 @@ struct UNetRun {
         c.ab = finalize(a, b, norm->gamma, norm->beta, ab_buf);  // (may attach itself to the pending producer)
     }
     flush_conv(pend, s);
+    if (g_modes.conv == CONV_ARITH_HX2 && g_modes.pipelined && g_modes.wino && hx2w_pays(c) && conv_hx2w_supported(c, mode)) h->wino_convs += 1;
     pend.valid = true, pend.c = c, pend.mode = mode;
     pend.flops = conv_flops(B, So * So, w.cout, kprod);
     return o;
@@ -763,7 +789,7 @@ struct UNetRun {
     const rgfm_unet_desc& d = h->d;
     ModeScope mode_scope(h->conv_mode);
     if (!dry && h->trace) h->acts.clear();
-    if (!dry) h->p_handovers = 0;
+    if (!dry) h->p_handovers = 0, h->wino_convs = 0;
     int S = d.img_size;
     Tensor cur = new_tensor(h->mc, S);
     if (!dry) {

@@ -149,6 +149,9 @@ struct ConvArgs {
   int fin_C1;
   const float* fin_gamma;    // [Cout + fin_C1]
   const float* fin_beta;
+  // Winograd F(2x2, 3x3) image of the same 3x3 weights (conv_mfma_hx2w.hip: launch_pack_conv_hx2w) and its scale record, or null
+  const void* wpkw;
+  const float* hqw;
   int B, Cout;
   TileGeom g;        // OUTPUT raster tiling
   int halo_px;       // pixels of the staged input tile
@@ -274,6 +277,13 @@ void launch_up2_as_deconv(const float* w, float* k, int Cout, int Cin, hipStream
 // packs w (mode CONV_S1: [Cout][Cin][taps]; CONV_S2: the phase-major stride-2 order; CONV_T2: a ConvTranspose2d
 // weight [Cin][Cout][4][4], taps ignored) and writes the scale record hq[4] (device)
 void launch_pack_conv_hx2(const float* w, void* out, float* hq, int Cout, int Cin, int taps, int mode, hipStream_t s);
+
+// Winograd F(2x2, 3x3) form of the stride-1 3x3 conv on the two-plane arithmetic (conv_mfma_hx2w.hip); its own packed weights
+void hx2_scale_launch(const float* w, size_t n, float* hq, hipStream_t s);
+void launch_pack_conv_hx2w(const float* w, void* out, float* hq, float* tmp, int Cout, int Cin, hipStream_t s);
+bool conv_hx2w_supported(const ConvArgs& a, int mode);
+int conv_hx2w_init();
+void launch_conv_hx2w(const ConvArgs& a, hipStream_t s);
 
 void launch_conv_in(const ConvInArgs& a, int cin, hipStream_t s);
 void launch_conv_out(const ConvOutArgs& a, int cimg, hipStream_t s);

@@ -74,7 +74,8 @@ def test_unet_ragged_batches(dev, tag, B):
 
 
 @pytest.mark.parametrize("tag", ["g24", "g16", "g40"])
-@pytest.mark.parametrize("env", [{}, {"RGFM_CONV": "bx3"}, {"RGFM_CONV": "f32"}, {"RGFM_GN": "table"}, {"RGFM_HX2D": "0"}, {"RGFM_UP_T2": "0"}])
+@pytest.mark.parametrize("env", [{}, {"RGFM_CONV": "bx3"}, {"RGFM_CONV": "f32"}, {"RGFM_GN": "table"}, {"RGFM_HX2D": "0"}, {"RGFM_UP_T2": "0"},
+                                 {"RGFM_WINO": "1"}])
 def test_generic_flexible_unets(dev, tag, env, monkeypatch):
     """FlexibleUNet shapes outside the presets -- 24x24 (three tiles per sample: tile pairs straddle samples, 12
     statistics parts), 16x16 with four levels down to 2x2 maps and three blocks per level, 40x40 (tiles of 6 rows,
@@ -417,7 +418,9 @@ def test_full_size_arithmetic_modes_agree(dev, monkeypatch):
                                  # the P-format hand-over conv1 -> conv2 (conv_mfma_hx2d.hip): off, and each of its two cuts everywhere
                                  {"RGFM_HX2D": "0"}, {"RGFM_HX2D": "1"}, {"RGFM_HX2D": "2"},
                                  # the Upsample convs as nine taps over the upsampled raster instead of four parity classes
-                                 {"RGFM_UP_T2": "0"}, {"RGFM_UP_T2": "0", "RGFM_GN": "table"}])
+                                 {"RGFM_UP_T2": "0"}, {"RGFM_UP_T2": "0", "RGFM_GN": "table"},
+                                 # the opt-in Winograd F(2x2, 3x3) form of the long-K stride-1 convs (conv_mfma_hx2w.hip)
+                                 {"RGFM_WINO": "1"}, {"RGFM_WINO": "1", "RGFM_GN": "table"}, {"RGFM_WINO": "1", "RGFM_HX2D": "0"}])
 @pytest.mark.parametrize("tag,B", [("svhn", 5), ("mnist32", 3)])
 def test_conv_variants_keep_parity(dev, env, tag, B, monkeypatch):
     """The alternative conv arithmetic (RGFM_CONV=bx3: three exact bf16 planes, the fp32-range fallback of the
@@ -707,6 +710,34 @@ def test_guidance_late_time_concentrated_weights(dev):
         dvx, dvy = maxdiff(gvx.cpu().numpy(), ovx), maxdiff(gvy.cpu().numpy(), ovy)
         print(f"t={t} gamma={gamma}: |dv| {dvx:.2e} {dvy:.2e}  bound {bound:.2e}  |v| {float(np.abs(ovy).max()):.1f}")
         assert dvx < bound and dvy < bound, (t, dvx, dvy, bound)
+
+
+def test_winograd_form_of_the_long_k_convs(dev, monkeypatch):
+    """RGFM_WINO=1: the stride-1 3x3 convs with 128 or more input channels at the 16x16 / 32x32 levels (no fused 1x1 skip)
+    run as Winograd F(2x2, 3x3) on the two-plane arithmetic (conv_mfma_hx2w.hip: 4 / 9 of the products; transforms in fp32,
+    split after the input transform).  Same tolerance as every other path, against the oracle; the path is really taken
+    (rgfm_unet_wino_convs); rows do not depend on the batch they are evaluated in (bitwise)."""
+    import ctypes
+    m = make_module("svhn", dev)
+    desc, blob = oracle_net("svhn")
+    B = 21
+    x = torch.randn(B, *SHAPES["svhn"], generator=torch.Generator().manual_seed(19))
+    t = torch.rand(B, generator=torch.Generator().manual_seed(20))
+    base = m(x.to(dev), t.to(dev))
+    monkeypatch.setenv("RGFM_WINO", "1")
+    out = m(x.to(dev), t.to(dev))
+    n = ctypes.c_int()
+    _lib.check(_lib.lib().rgfm_unet_wino_convs(m._engine.handle(dev), ctypes.byref(n)))
+    # enc3.conv1 / conv2 (128 -> 128 at 16x16), dec3-5.conv1 (256 / 256 / 192 -> 128), dec6-8.conv1 (192 / 128 / 128 -> 64 at 32x32)
+    assert n.value == 8, n.value
+    part = m(x[3:8].to(dev), t[3:8].to(dev))
+    assert torch.equal(out[3:8], part)
+    idx = [0, 7, 20]
+    ro = O.unet_forward(desc, blob, x.numpy()[idx], t.numpy()[idx])
+    assert maxdiff(out.cpu().numpy()[idx], ro) < TOL_EVAL
+    d = float((out - base).abs().max())
+    print(f"Winograd path vs default path: max|diff| {d:.2e}")
+    assert 0.0 < d < 1e-5
 
 
 @pytest.mark.parametrize("tag", ["mnist32", "svhn"])

@@ -24,6 +24,9 @@ ALLOW = {
     "conv_mfma_hx2p_kernel<2, 0, 2, true>": (44, "under-filled launches only; prologue values"),
     # the P-format producer twin of the two-tile kernel (MNIST net's 16x16 conv1 layers): 3 dwords around the epilogue
     "conv_mfma_hx2p_kernel<2, 0, 0, true>": (12, "epilogue of the P-format producer"),
+    # the Winograd kernel: up to four dwords of the epilogue's addressing saved in the prologue, restored behind the K loop
+    "conv_mfma_hx2w_kernel<4>": (16, "epilogue addressing, outside the K loop"),
+    "conv_mfma_hx2w_kernel<5>": (16, "epilogue addressing, outside the K loop"),
 }
 
 

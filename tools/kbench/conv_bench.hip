@@ -26,6 +26,7 @@
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2s.hip"
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2c.hip"
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2d.hip"
+#include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2w.hip"
 #include "../../ratio_guided_multimodal_fm_amd/csrc/unet_kernels.hip"
 
 using namespace rgfm;
@@ -71,6 +72,7 @@ int main(int argc, char** argv) {
   const bool hx2s = argc > 7 && strcmp(argv[7], "hx2s") == 0;
   const bool hx2c = argc > 7 && strcmp(argv[7], "hx2c") == 0;
   const bool hx2d = argc > 7 && strcmp(argv[7], "hx2d") == 0;
+  const bool hx2w = argc > 7 && strcmp(argv[7], "hx2w") == 0;  // Winograd F(2x2, 3x3) on the two-plane arithmetic
   const int Sin = mode == CONV_UP2 ? S / 2 : (mode == CONV_S2 ? 2 * S : S);
   const int nt = Cout % 64 == 0 ? 2 : 1;
   CK(hipSetDevice(0));
@@ -204,6 +206,19 @@ int main(int argc, char** argv) {
     hipMalloc(&pob, (size_t)B * S * S * Cout * 4);
     ap.pout = pob, ap.pn_gamma = dev_rand(Cout, 1.f, 31), ap.pn_beta = dev_rand(Cout, 0.3f, 32);
   }
+  ConvArgs aw = a;  // conv_mfma_hx2w_kernel: its own packed (transformed) weights and scale record
+  if (hx2w) {
+    void* whw;
+    float *hqw, *tmpw;
+    hipMalloc(&whw, (size_t)Cout * Cin * 16 * 4);
+    hipMalloc(&hqw, 8 * sizeof(float));
+    hipMalloc(&tmpw, (size_t)Cout * Cin * 16 * 4);
+    launch_pack_conv_hx2w(w, whw, hqw, tmpw, Cout, Cin, 0);
+    aw.wpkw = whw, aw.hqw = hqw;
+    if (getenv("RGFM_KB_GN")) aw = ap, aw.wpkw = whw, aw.hqw = hqw;  // the consumer-side norm (statistics) instead of the array
+    CK(hipDeviceSynchronize());
+    if (conv_hx2w_init() != 0 || !conv_hx2w_supported(aw, mode)) { printf("hx2w: unsupported shape\n"); return 1; }
+  }
   if (hx2p && !conv_hx2p_supported(ap, mode)) { printf("hx2p: unsupported shape\n"); return 1; }
   if (hx2q && !conv_hx2q_supported(ap, mode)) { printf("hx2q: unsupported shape\n"); return 1; }
   if (hx2s && !conv_hx2s_supported(a, mode)) { printf("hx2s: unsupported shape\n"); return 1; }
@@ -216,6 +231,7 @@ int main(int argc, char** argv) {
     else if (hx2s) launch_conv_hx2s(a, 0);
     else if (hx2c) launch_conv_hx2c(ap, 0);
     else if (hx2d) launch_conv_hx2d(ad, 0);
+    else if (hx2w) launch_conv_hx2w(aw, 0);
     else launch_conv_bx3(a, mode, 0);
   };
   {  // reference: the exact-fp32 MFMA kernel on the same data
@@ -276,7 +292,7 @@ int main(int argc, char** argv) {
   float ms;
   hipEventElapsedTime(&ms, e0, e1);
   const double us = ms * 1e3 / reps;
-  printf("%s S=%d Cin=%d Cout=%d mode=%d res=%d B=%d: %8.1f us  %6.1f TFLOP/s (fp32-equivalent)\n", f32 ? "f32" : (hx2 ? "hx2" : (hx2p ? "hx2p" : (hx2q ? "hx2q" : (hx2s ? "hx2s" : (hx2c ? "hx2c" : (hx2d ? "hx2d" : "bx3")))))), S, Cin,
+  printf("%s S=%d Cin=%d Cout=%d mode=%d res=%d B=%d: %8.1f us  %6.1f TFLOP/s (fp32-equivalent)\n", f32 ? "f32" : (hx2 ? "hx2" : (hx2p ? "hx2p" : (hx2q ? "hx2q" : (hx2s ? "hx2s" : (hx2c ? "hx2c" : (hx2d ? "hx2d" : (hx2w ? "hx2w" : "bx3"))))))), S, Cin,
          Cout, mode, res, B, us, flops / us / 1e6);
 #ifdef RGFM_HX2Q_PROF
   if (hx2q) {

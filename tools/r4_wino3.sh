@@ -1,0 +1,6 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT/tools/kbench; O=$GRAFT_REPO_ROOT/gpurun_out
+( for B in 512 256; do for a in "16 128 128 0 0" "16 128 128 0 1" "16 256 128 0 0" "16 192 128 0 0" "32 192 64 0 0" "32 128 64 0 0" "16 128 64 0 0"; do
+  for w in hx2w hx2p; do echo -n "$a $B $w: "; RGFM_KB_GN=1 REPS=${REPS:-300} timeout -k 10 60 ./conv_bench_w $a $B $w 2>&1 | tr "\n" " "; echo; done
+done; done ) > $O/r4_wino3.txt 2>&1
+sed 's/check vs f32 kernel: max|diff| //; s/stats rel diff //; s/(fp32-equivalent)//; s/range flag 0 //' $O/r4_wino3.txt | cut -c1-200
