@@ -324,7 +324,10 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2w_kernel(const ConvArgs a
   // Two re-orderings were measured against this on 512-row launches (profiles/r04_kbench/hx2w_vs_direct.txt): the two groups
   // of four waves half a chunk apart (one group's transform under the other's MFMAs, R double-buffered): 11.3 instead of
   // 9.1 us per chunk -- a transform wave alone on its SIMD is latency-bound; the next chunk's staging under this chunk's
-  // MFMAs: 128.9 instead of 123.9 us for 16x16 128 -> 128 -- exp / rcp beside MFMAs slow both.
+  // MFMAs: 128.9 instead of 123.9 us for 16x16 128 -> 128 -- exp / rcp beside MFMAs slow both.  A third: FOUR waves (one per
+  // SIMD, the accumulators of four positions in the accumulation registers) with the transform of chunk c + 1 between the
+  // MFMAs of chunk c in one instruction stream, V double-buffered (tools/experiments/conv_mfma_hx2w4.hip; bit-identical):
+  // 150.6 against 123.6 us -- one wave per SIMD has nobody to hide its LDS round trips and its exp / rcp phase behind.
   __syncthreads();  // the table
 #pragma unroll 1
   for (int c = 0; c < nch; ++c) {
@@ -447,6 +450,7 @@ bool conv_hx2w_supported(const ConvArgs& a, int mode) {
 
 int conv_hx2w_init() {
   int rc = 0;
+
   rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_hx2w_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_hx2w_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   return rc;

@@ -27,6 +27,9 @@
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2c.hip"
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2d.hip"
 #include "../../ratio_guided_multimodal_fm_amd/csrc/conv_mfma_hx2w.hip"
+#ifdef RGFM_KB_HX2W4
+#include "../experiments/conv_mfma_hx2w4.hip"  // the rejected four-wave cut (RGFM_HX2W_CUT=2)
+#endif
 #include "../../ratio_guided_multimodal_fm_amd/csrc/unet_kernels.hip"
 
 using namespace rgfm;
@@ -218,6 +221,9 @@ int main(int argc, char** argv) {
     if (getenv("RGFM_KB_GN")) aw = ap, aw.wpkw = whw, aw.hqw = hqw;  // the consumer-side norm (statistics) instead of the array
     CK(hipDeviceSynchronize());
     if (conv_hx2w_init() != 0 || !conv_hx2w_supported(aw, mode)) { printf("hx2w: unsupported shape\n"); return 1; }
+#ifdef RGFM_KB_HX2W4
+    conv_hx2w4_init();
+#endif
   }
   if (hx2p && !conv_hx2p_supported(ap, mode)) { printf("hx2p: unsupported shape\n"); return 1; }
   if (hx2q && !conv_hx2q_supported(ap, mode)) { printf("hx2q: unsupported shape\n"); return 1; }
@@ -231,6 +237,9 @@ int main(int argc, char** argv) {
     else if (hx2s) launch_conv_hx2s(a, 0);
     else if (hx2c) launch_conv_hx2c(ap, 0);
     else if (hx2d) launch_conv_hx2d(ad, 0);
+#ifdef RGFM_KB_HX2W4
+    else if (hx2w && getenv("RGFM_HX2W_CUT") && atoi(getenv("RGFM_HX2W_CUT")) == 2) launch_conv_hx2w4(aw, 0);
+#endif
     else if (hx2w) launch_conv_hx2w(aw, 0);
     else launch_conv_bx3(a, mode, 0);
   };
