@@ -346,7 +346,8 @@ inline bool p_producer_ok(const ConvArgs& c, int mode) {
 // costs less per chunk than the direct kernels', its epilogue (the output transform through LDS) more -- so the long-K
 // layers: 128 or more input channels.  By layer shape only, never by batch.
 inline bool hx2w_pays(const ConvArgs& c) {
-  return c.wpkw != nullptr && c.C0 + c.C1 >= 128;
+  static const int w32_only = getenv("RGFM_WINO_W32") ? atoi(getenv("RGFM_WINO_W32")) : 0;  // (A/B: the 32x32 layers only)
+  return c.wpkw != nullptr && c.C0 + c.C1 >= 128 && (!w32_only || c.g.W == 32);
 }
 
 inline void launch_conv(const ConvArgs& c, int mode, hipStream_t s) {
