@@ -317,6 +317,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",  # fp32 tensors and accumulation end to end; how the conv products are formed: "arithmetic"
             "arithmetic": ARITHMETIC.get(conv_mode, conv_mode),
+            # optional kernel paths of the default arithmetic as this run had them (environment switches)
+            "conv_paths": {"upsample_as_parity_classes": conv_mode == "hx2" and os.environ.get("RGFM_UP_T2", "1") != "0",
+                           "p_format_hand_over": conv_mode == "hx2" and os.environ.get("RGFM_HX2D", "3") != "0",
+                           "winograd": conv_mode == "hx2" and os.environ.get("RGFM_WINO", "0") == "1"},
             "range_fallbacks": _engine.range_fallbacks,  # calls repeated on the split-bf16 convs by the fp16 range guard (0: none)
             "data": "synthetic",
             "config": {

@@ -712,6 +712,31 @@ def test_guidance_late_time_concentrated_weights(dev):
         assert dvx < bound and dvy < bound, (t, dvx, dvy, bound)
 
 
+@pytest.mark.parametrize("tag", ["mnist32", "svhn"])
+def test_upsample_convs_as_parity_classes(dev, tag, monkeypatch):
+    """Upsample.forward = conv3x3(nearest_x2(x)) (unet_flexible.py:107-108) runs as the algebraically identical
+    ConvTranspose2d(4, 2, 1) -- four 2x2-tap parity classes over the input raster, kernel rows / columns that land on the same
+    source pixel added at create (4 / 9 of the products).  Against the nine-tap form (RGFM_UP_T2=0) only fp32 rounding may
+    differ: both match the oracle, they differ from each other by far less than the tolerance but not by nothing (the path is
+    taken), and rows do not depend on their batch."""
+    m = make_module(tag, dev)
+    desc, blob = oracle_net(tag)
+    B = 11
+    x = torch.randn(B, *SHAPES[tag], generator=torch.Generator().manual_seed(29))
+    t = torch.rand(B, generator=torch.Generator().manual_seed(30))
+    out = m(x.to(dev), t.to(dev))
+    part = m(x[2:6].to(dev), t[2:6].to(dev))
+    assert torch.equal(out[2:6], part)
+    monkeypatch.setenv("RGFM_UP_T2", "0")
+    nine = m(x.to(dev), t.to(dev))
+    monkeypatch.delenv("RGFM_UP_T2")
+    ro = O.unet_forward(desc, blob, x.numpy(), t.numpy())
+    assert maxdiff(out.cpu().numpy(), ro) < TOL_EVAL and maxdiff(nine.cpu().numpy(), ro) < TOL_EVAL
+    d = float((out - nine).abs().max())
+    print(f"{tag}: parity classes vs nine taps: max|diff| {d:.2e}")
+    assert 0.0 < d < 3e-6, d
+
+
 def test_winograd_form_of_the_long_k_convs(dev, monkeypatch):
     """RGFM_WINO=1: the stride-1 3x3 convs with 128 or more input channels at the 16x16 / 32x32 levels (no fused 1x1 skip)
     run as Winograd F(2x2, 3x3) on the two-plane arithmetic (conv_mfma_hx2w.hip: 4 / 9 of the products; transforms in fp32,
