@@ -328,6 +328,9 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2w_kernel(const ConvArgs a
   // SIMD, the accumulators of four positions in the accumulation registers) with the transform of chunk c + 1 between the
   // MFMAs of chunk c in one instruction stream, V double-buffered (tools/experiments/conv_mfma_hx2w4.hip; bit-identical):
   // 150.6 against 123.6 us -- one wave per SIMD has nobody to hide its LDS round trips and its exp / rcp phase behind.
+  // And a tile loop per workgroup (four tiles; the samples' tables made once, side by side on the waves; a tile's first halo
+  // request issued before the previous tile's epilogue): 123.6 -> 120.6 us at 16x16, +-0 at 32x32, for 108 bytes of scratch
+  // (profiles/r04_kbench/hx2w_tile_loop.txt) -- not kept: the fixed 10 us per tile are the epilogue's two passes, not the prologue.
   __syncthreads();  // the table
 #pragma unroll 1
   for (int c = 0; c < nch; ++c) {
