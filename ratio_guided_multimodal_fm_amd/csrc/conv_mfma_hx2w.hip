@@ -408,13 +408,17 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2w_kernel(const ConvArgs a
     __syncthreads();
     if (tid < 128 && a.stats_out && sample_ok) {  // (part, channel): 16 tiles = 64 pixels, combined in tile order
       const int part = tid >> 5, co = tid & 31;
-      double n = 0.0, mean = 0.0, m2 = 0.0;
+      // (unrolled: the sixteen reads go out together and the weights 4 / n, 4 (n - 4) / n are constants -- as a loop this was
+      // sixteen dependent LDS round trips and thirty-two fp64 divisions on two waves while six waited at the next barrier)
+      float2 sv[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) sv[k] = *reinterpret_cast<const float2*>(sS + ((size_t)(16 * part + k) * 32 + co) * 2);
+      double mean = 0.0, m2 = 0.0;
+#pragma unroll
       for (int k = 0; k < 16; ++k) {
-        const float2 v = *reinterpret_cast<const float2*>(sS + ((size_t)(16 * part + k) * 32 + co) * 2);
-        const double d = (double)v.x - mean, nn = n + 4.0;
-        mean += d * (4.0 / nn);
-        m2 += (double)v.y + d * d * (n * 4.0 / nn);
-        n = nn;
+        const double d = (double)sv[k].x - mean;
+        mean += d * (1.0 / (double)(k + 1));
+        m2 += (double)sv[k].y + d * d * (4.0 * (double)k / (double)(k + 1));
       }
       const int gpart = (tile - b0 * g.tps) * 4 + part;
       float2 o;
