@@ -270,29 +270,39 @@ __global__ __launch_bounds__(512, 2) void conv_mfma_hx2w_kernel(const ConvArgs a
       const int off = (((i & 1) * 2 + (j & 1)) * PSZ + (i >> 1) * PW + (j >> 1)) * HX2W_RREC;
       return *reinterpret_cast<const f32x4*>(rb + off);
     };
-    f32x4 t0[4], t1[4];
+    // (on float2 halves: v_pk_add_f32, two channels per instruction -- this phase has no MFMAs beside it)
+    struct P2 {
+      hx_f32x2 lo, hi;
+    };
+    auto ld = [&](int i, int j) -> P2 {
+      const f32x4 v = rd(i, j);
+      return P2{hx_f32x2{v.x, v.y}, hx_f32x2{v.z, v.w}};
+    };
+    auto sub = [](const P2& x, const P2& y) { return P2{x.lo - y.lo, x.hi - y.hi}; };
+    auto add = [](const P2& x, const P2& y) { return P2{x.lo + y.lo, x.hi + y.hi}; };
+    P2 t0[4], t1[4];
     if (grp == 0) {  // rows 0, 1 of B^T d: d0 - d2, d1 + d2
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const f32x4 d0 = rd(0, j), d1 = rd(1, j), d2 = rd(2, j);
-        t0[j] = d0 - d2, t1[j] = d1 + d2;
+        const P2 d0 = ld(0, j), d1 = ld(1, j), d2 = ld(2, j);
+        t0[j] = sub(d0, d2), t1[j] = add(d1, d2);
       }
     } else {  // rows 2, 3: d2 - d1, d1 - d3
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const f32x4 d1 = rd(1, j), d2 = rd(2, j), d3 = rd(3, j);
-        t0[j] = d2 - d1, t1[j] = d1 - d3;
+        const P2 d1 = ld(1, j), d2 = ld(2, j), d3 = ld(3, j);
+        t0[j] = sub(d2, d1), t1[j] = sub(d1, d3);
       }
     }
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      const f32x4* t = r ? t1 : t0;
-      const f32x4 v[4] = {t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]};
+      const P2* t = r ? t1 : t0;
+      const P2 v[4] = {sub(t[0], t[2]), add(t[1], t[2]), sub(t[2], t[1]), sub(t[1], t[3])};
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
         unsigned h0, l0, h1, l1;
-        hsplit2(v[cc].x, v[cc].y, h0, l0);
-        hsplit2(v[cc].z, v[cc].w, h1, l1);
+        hsplit2(v[cc].lo.x, v[cc].lo.y, h0, l0);
+        hsplit2(v[cc].hi.x, v[cc].hi.y, h1, l1);
         const hx_u32x2 ph = {h0, h1}, pl = {l0, l1};
         *reinterpret_cast<hx_u32x2*>(sV + vdst_h + (r * 4 + cc) * (64 * HRW)) = ph;
         *reinterpret_cast<hx_u32x2*>(sV + vdst_l + (r * 4 + cc) * (64 * HRW)) = pl;
